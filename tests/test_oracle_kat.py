@@ -1,0 +1,184 @@
+"""Known-answer tests that pin the CPU oracle to the reference's source text.
+
+The reference has no tests or fixtures; every expected value below is derived by
+hand from calc/src/lib.rs with exactly representable inputs.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def test_kat1_escape_index_and_position():
+    # recursive (calc/src/lib.rs:245-257): 2 -> 6 -> 38 -> 1446 -> 2090918; 2090918^2 > 2^32 at i = 3
+    assert O.recursive(50, (2, 0), (2, 0), 65536) == ((2090918.0, 0.0), 3)
+
+
+def test_kat2_limit_is_a_radius_squared_inside():
+    # limit = 2 => squared = 4; first `next` = 6, 36 > 4 => (next, 0)
+    assert O.recursive(50, (2, 0), (2, 0), 2) == ((6.0, 0.0), 0)
+
+
+def test_kat3_bounded_orbit_returns_previous_and_iterations():
+    # c = -2: z = 2 forever, never > 2^32; exhaustion returns (previous, iterations) (:256)
+    assert O.recursive(50, (-2, 0), (-2, 0), 65536) == ((2.0, 0.0), 50)
+
+
+def test_kat3_bounded_orbit_is_coloured_as_outside():
+    # dist = 4 > stable_limit = 2 (stable_limit is compared with the SQUARED distance, :216)
+    cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25))
+    # pixel (0, 2) is exactly -2 + 0i: x/H - (W/H)/2 = 0 - 0.5, /0.25 = -2; y: 2/4 - 0.5 = 0
+    z = O.lib().fro_xy_to_imaginary(cfg, 0, 2)
+    assert (z.re, z.im) == (-2.0, 0.0)
+    # smooth: log_zn = log2(2)/2 = 0.5, nu = -1, it = 52, mult = 52/50*2 = 2.08 -> (83, 83, 255)
+    assert O.get_recursive_pixel(cfg, 0, 2) == (83, 83, 255)
+    cfg.smooth = 0  # mult = 50/50*2 = 2 -> (80, 80, 255 saturated)
+    assert O.get_recursive_pixel(cfg, 0, 2) == (80, 80, 255)
+
+
+def test_kat4_period_two_orbit():
+    assert O.recursive(50, (-1, 0), (-1, 0), 65536) == ((-1.0, 0.0), 50)
+    assert O.recursive(51, (-1, 0), (-1, 0), 65536) == ((0.0, 0.0), 51)
+    cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25))
+    assert O.get_recursive_pixel(cfg, 1, 2) == (240, 170, 0)  # inside colour: secondary * dist(=1)
+    cfg.iterations = 51
+    assert O.get_recursive_pixel(cfg, 1, 2) == (0, 0, 0)  # secondary * 0
+
+
+def test_kat5_origin():
+    for n in (0, 1, 50):
+        assert O.recursive(n, (0, 0), (0, 0), 65536) == ((0.0, 0.0), n)
+
+
+def test_kat6_rgb_new_argument_order():
+    # RGB::new(r, b, g) (calc/src/lib.rs:129-131): the SECOND argument is blue
+    c = O.lib().fro_rgb_new(40, 40, 255)
+    assert (c.r, c.g, c.b) == (40, 255, 40)
+    c = O.lib().fro_rgb_new(240, 170, 0)
+    assert (c.r, c.g, c.b) == (240, 0, 170)
+    cfg = O.config_new()
+    assert cfg.primary_color.bytes() == (40, 255, 40)
+    assert cfg.secondary_color.bytes() == (240, 0, 170)
+
+
+def test_config_new_defaults():
+    cfg = O.config_new()
+    assert (cfg.width, cfg.height, cfg.iterations) == (2000, 1000, 50)
+    assert (cfg.limit, cfg.stable_limit, cfg.exposure) == (65536.0, 2.0, 2.0)
+    assert (cfg.scale.re, cfg.scale.im) == (0.4, 0.4)
+    assert (cfg.inside, cfg.smooth) == (1, 1)
+    fern = O.config_new(O.BARNSLEY_FERN)
+    assert fern.iterations == 10_000_000
+    assert fern.primary_color.bytes() == (4, 3, 100)  # new(4, 100, 3) -> {r4, g3, b100}
+
+
+KAT7_SMOOTH = [
+    [(0, 0, 5), (1, 1, 8), (1, 1, 9), (0, 0, 6)],
+    [(1, 1, 12), (3, 3, 22), (240, 170, 0), (2, 2, 13)],
+    [(83, 83, 255), (240, 170, 0), (0, 0, 0), (2, 2, 18)],
+    [(1, 1, 12), (3, 3, 22), (240, 170, 0), (2, 2, 13)],
+]
+KAT7_UNSMOOTH = [
+    [(4, 4, 30)] * 4,
+    [(6, 6, 40), (8, 8, 51), (240, 170, 0), (6, 6, 40)],
+    [(80, 80, 255), (240, 170, 0), (0, 0, 0), (6, 6, 40)],
+    [(6, 6, 40), (8, 8, 51), (240, 170, 0), (6, 6, 40)],
+]
+
+
+@pytest.mark.parametrize("mode", [O.LOG2_LIBM, O.LOG2_SOFT])
+def test_kat7_4x4_image(mode):
+    # W = H = 4, scale 0.25: pixel starts are exactly {-2,-1,0,1}^2; Config::new colours, exposure 2
+    O.set_log2_mode(mode)
+    try:
+        cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25))
+        img = O.get_image(cfg)
+        assert img.shape == (4, 4, 3)
+        assert [[tuple(p) for p in row] for row in img.tolist()] == KAT7_SMOOTH
+        cfg.smooth = 0  # libm-free variant
+        img = O.get_image(cfg)
+        assert [[tuple(p) for p in row] for row in img.tolist()] == KAT7_UNSMOOTH
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+
+
+def test_x_is_divided_by_height():
+    # xy_to_imaginary (calc/src/lib.rs:186-197): re = (x/H - (W/H)/2)/scale + pos — square pixels
+    cfg = O.config_new(width=8, height=4, scale=(0.5, 0.5), pos=(0.25, -0.125))
+    z = O.lib().fro_xy_to_imaginary(cfg, 8, 4)  # one past the last pixel: x/H = 2, offset 1
+    assert (z.re, z.im) == ((2.0 - 1.0) / 0.5 + 0.25, (1.0 - 0.5) / 0.5 - 0.125)
+    z = O.lib().fro_xy_to_imaginary(cfg, 0, 0)
+    assert (z.re, z.im) == (-1.0 / 0.5 + 0.25, -0.5 / 0.5 - 0.125)
+
+
+def test_as_u8_saturation_nan_and_negative():
+    # exposure huge -> saturate at 255; stable_limit < dist < 1 -> log2(negative) = NaN -> 0
+    cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25), exposure=1e9)
+    assert O.get_recursive_pixel(cfg, 0, 2) == (255, 255, 255)
+    cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25), stable_limit=0.5, iterations=50)
+    # pixel (1,2) is c = -1: final z = -1, dist = 1 > 0.5: log_zn = log2(1)/2 = 0, nu = -inf, it = +inf
+    assert O.get_recursive_pixel(cfg, 1, 2) == (255, 255, 255)
+    # negative multiplier -> 0 (Rust `as u8` saturates at 0)
+    cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25), exposure=-3.0)
+    assert O.get_recursive_pixel(cfg, 0, 2) == (0, 0, 0)
+
+
+def test_julia_uses_constant_c():
+    # Julia: c = config.julia_set for every pixel (calc/src/lib.rs:210)
+    cfg = O.config_new(O.JULIA, width=4, height=4, scale=(0.25, 0.25), julia_set=(-1.0, 0.0), iterations=51)
+    # pixel (2,2) starts at 0: 0 -> -1 -> 0 ... after 51 steps z = -1 (odd count)
+    z, it = O.escape_rows(cfg)
+    assert it[2, 2] == 51 and tuple(z[2, 2]) == (-1.0, 0.0)
+    pos, n = O.recursive(51, (0, 0), (-1, 0), 65536)
+    assert (pos, n) == ((-1.0, 0.0), 51)
+
+
+def test_fern_is_black_on_this_path():
+    cfg = O.config_new(O.BARNSLEY_FERN, width=5, height=3)
+    assert not O.get_image(cfg).any()
+
+
+def test_f32_fast_path_definition():
+    # build-defined (no f32 in the reference): same op order in binary32
+    f = np.float32
+    re, im = f(0.3), f(0.5)
+    cre, cim = re, im
+    for i in range(5):
+        nre = f(f(f(re * re) - f(im * im)) + cre)
+        nim = f(f(f(f(2.0) * re) * im) + cim)
+        re, im = nre, nim
+    pos, n = O.recursive(5, (0.3, 0.5), (0.3, 0.5), 65536, f32=True)
+    assert n == 5 and pos == (float(re), float(im))
+
+
+def test_executed_iteration_count_definition():
+    # escape at index i executed i+1 iterations; exhaustion executed `iterations`
+    cfg = O.config_new(width=4, height=4, scale=(0.25, 0.25))
+    _, it = O.escape_rows(cfg)
+    expect = int(np.where(it < 50, it.astype(np.int64) + 1, 50).sum())
+    assert O.count_iterations(cfg) == expect
+    total, npx, _ = O.sample_image(cfg, 1, 1)
+    assert (total, npx) == (expect, 16)
+
+
+def test_soft_log2_tracks_libm():
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([np.exp(rng.uniform(-700, 700, 5000)), rng.uniform(0.5, 2, 5000),
+                         1 + rng.uniform(-0.05, 0.05, 5000), rng.uniform(8, 16, 5000)])
+    worst = 0
+    for x in xs.tolist():
+        O.set_log2_mode(O.LOG2_LIBM)
+        a = np.float64(O.log2(x)).view(np.int64)
+        O.set_log2_mode(O.LOG2_SOFT)
+        b = np.float64(O.log2(x)).view(np.int64)
+        worst = max(worst, abs(int(a) - int(b)))
+    O.set_log2_mode(O.LOG2_LIBM)
+    assert worst <= 1
+    for x, want in [(0.0, -math.inf), (-0.0, -math.inf), (math.inf, math.inf), (1.0, 0.0), (2.0, 1.0),
+                    (0.5, -1.0), (65536.0, 16.0), (5e-324, -1074.0)]:
+        O.set_log2_mode(O.LOG2_SOFT)
+        assert O.log2(x) == want
+    assert math.isnan(O.log2(-1.0)) and math.isnan(O.log2(math.nan))
+    O.set_log2_mode(O.LOG2_LIBM)
