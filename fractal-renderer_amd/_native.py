@@ -1,0 +1,147 @@
+"""ctypes loader of libfractal_hip.so (the C ABI of include/fractal_hip.h).
+
+There is no fallback: a missing or unloadable library raises, and every compute call raises
+FractalHipError when the HIP path fails (no GPU, HIP error).
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libfractal_hip.so")
+
+FR_OK, FR_ERR_INVALID_ARGUMENT, FR_ERR_BUFFER_TOO_SMALL, FR_ERR_NO_DEVICE, FR_ERR_HIP = 0, 1, 2, 3, 4
+STATUS_NAMES = {
+    1: "FR_ERR_INVALID_ARGUMENT",
+    2: "FR_ERR_BUFFER_TOO_SMALL",
+    3: "FR_ERR_NO_DEVICE",
+    4: "FR_ERR_HIP",
+    5: "FR_ERR_UNSUPPORTED_ALGO",
+}
+
+
+class FractalHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(code, "fr_status %d" % code), message))
+        self.code = code
+
+
+class Imaginary(C.Structure):
+    """calc/src/lib.rs:79-82"""
+
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+    def __iter__(self):
+        return iter((self.re, self.im))
+
+
+class RGB(C.Structure):
+    """calc/src/lib.rs:121-125 — the stored fields (see RGB.new for the constructor quirk)."""
+
+    _fields_ = [("r", C.c_uint8), ("g", C.c_uint8), ("b", C.c_uint8)]
+
+    @classmethod
+    def new(cls, r, b, g):
+        """RGB::new(r, b, g) — calc/src/lib.rs:129-131: the second parameter is BLUE."""
+        return cls(r, g, b)
+
+    def __iter__(self):
+        return iter((self.r, self.g, self.b))
+
+    def __eq__(self, other):
+        return tuple(self) == tuple(other)
+
+    def __repr__(self):
+        return "RGB { r: %d, g: %d, b: %d }" % tuple(self)
+
+
+class fr_config(C.Structure):
+    """include/fractal_hip.h fr_config == calc::Config (calc/src/lib.rs:21-37)."""
+
+    _fields_ = [
+        ("algo", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("iterations", C.c_uint32),
+        ("limit", C.c_double),
+        ("stable_limit", C.c_double),
+        ("pos", Imaginary),
+        ("scale", Imaginary),
+        ("exposure", C.c_double),
+        ("inside", C.c_uint8),
+        ("smooth", C.c_uint8),
+        ("primary_color", RGB),
+        ("secondary_color", RGB),
+        ("color_weight", C.c_double),
+        ("julia_set", Imaginary),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/fractal_hip.h declares
+PROTOTYPES = {
+    "fr_abi_version": (C.c_int, []),
+    "fr_init": (C.c_int, [C.c_int]),
+    "fr_shutdown": (C.c_int, []),
+    "fr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "fr_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "fr_last_error": (C.c_char_p, []),
+    "fr_config_new": (None, [C.POINTER(fr_config), C.c_uint32]),
+    "fr_render_rgb8": (C.c_int, [C.POINTER(fr_config), C.c_void_p, C.c_size_t]),
+    "fr_render_rows_rgb8": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "fr_render_rows_rgb8_device": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "fr_render_block_cyclic_rgb8_device": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
+         C.POINTER(C.c_uint64)],
+    ),
+    "fr_block_cyclic_rows": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "fr_pixel": (C.c_int, [C.POINTER(fr_config), C.c_uint32, C.c_uint32, C.POINTER(RGB)]),
+    "fr_pixel_p": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(RGB)]),
+    "fr_recursive": (
+        C.c_int,
+        [C.c_uint32, Imaginary, Imaginary, C.c_double, C.POINTER(Imaginary), C.POINTER(C.c_uint32)],
+    ),
+    "fr_recursive_batch": (
+        C.c_int,
+        [C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_void_p, C.c_void_p],
+    ),
+    "fr_escape_rows": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "fr_count_iterations": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+         C.POINTER(C.c_uint64)],
+    ),
+    "fr_set_profiling": (C.c_int, [C.c_int]),
+    "fr_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float)]),
+    "fr_set_tile": (C.c_int, [C.c_int]),
+    "fr_debug_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfractal_hip.so and bind every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing — build it first (python -c 'import __graft_entry__ as g; g.build()'); "
+            "this package has no CPU fallback" % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != FR_OK:
+        msg = load().fr_last_error()
+        raise FractalHipError(rc, msg.decode() if msg else "")

@@ -1,0 +1,56 @@
+/*
+ * fr_kernels.h — internal (C++) interface between the C ABI (fr_api.hip) and the gfx950 kernels
+ * (fr_kernels.hip).  Not installed; the public boundary is include/fractal_hip.h.
+ */
+#ifndef FR_KERNELS_H
+#define FR_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* Kernel arguments: calc::Config's hot-path fields (calc/src/lib.rs:21-37) plus the mapping from
+ * the launch's local pixel grid to image coordinates. */
+struct fr_kparams {
+    uint32_t algo;
+    uint32_t width, height; /* of the IMAGE (used by the coordinate map only) */
+    uint32_t iterations;
+    double limit, stable_limit;
+    double pos_re, pos_im, scale_re, scale_im;
+    double exposure;
+    double julia_re, julia_im;
+    uint32_t inside, smooth;
+    uint32_t prim[3], sec[3]; /* stored r, g, b fields of primary_color / secondary_color */
+    /* local grid: ncols x nrows pixels; local (cx, r) is image pixel
+     *   x = x_first + cx * x_stride
+     *   y = y_first + (r / block_rows) * y_stride + r % block_rows                     */
+    uint32_t ncols, nrows;
+    uint32_t x_first, x_stride;
+    uint32_t block_rows, y_first, y_stride;
+};
+
+enum fr_out_mode {
+    FR_OUT_RGB = 0,    /* packed r,g,b at 3*(r*ncols + cx)                    */
+    FR_OUT_ESCAPE = 1, /* z (2 doubles) and/or escape index per local pixel   */
+    FR_OUT_COUNT = 2   /* sum of executed iterations into one uint64          */
+};
+
+struct fr_kout {
+    uint8_t *rgb;
+    double *z;
+    uint32_t *iters;
+    unsigned long long *count;
+};
+
+/* tile = lanes_x*100 + lanes_y of the per-wave footprint; 0 = default */
+hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
+                            hipStream_t stream);
+
+/* n independent orbits, device arrays (re, im interleaved) */
+hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, const double *c, size_t n,
+                                     double limit, int precision, double *out_pos, uint32_t *out_iters,
+                                     hipStream_t stream);
+
+/* test hooks: elementwise device log2 / sqrt over n doubles */
+hipError_t fr_launch_math_probe(int which, const double *in, double *out, size_t n, hipStream_t stream);
+
+#endif

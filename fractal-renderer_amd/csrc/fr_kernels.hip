@@ -1,0 +1,313 @@
+/*
+ * fr_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the escape-time hot path.
+ *
+ * Written for gfx950 only.  MUST be compiled with -ffp-contract=off and without fast-math: the
+ * reference (Rust) rounds every multiply and add separately (calc/src/lib.rs:87-107), so a single
+ * v_fma_f64 in the orbit loop breaks bit parity.
+ *
+ * What runs where (reference lines in brackets):
+ *   coordinate map   [calc/src/lib.rs:181-197]  once per block COLUMN and block ROW, by the first
+ *                    lanes of the workgroup, staged in LDS — re depends only on x and im only on
+ *                    y, so the 3 IEEE f64 divisions per pixel of the reference become
+ *                    2 per column + 2 per row of a tile, with identical values;
+ *   orbit loop       [calc/src/lib.rs:245-257, 87-107]  one wavefront lane per pixel, state in
+ *                    VGPRs, exit when every lane of the wave has escaped (EXEC == 0) or the
+ *                    wave-uniform counter reaches `iterations`;
+ *   colour map       [calc/src/lib.rs:199-235, 133-139]  fused behind the loop; log2 is the
+ *                    software fr_log2 (fr_math.h) whose 3 KB table is staged in LDS;
+ *   image assembly   [src/lib.rs:253-270]  lane -> pixel mapping keeps each wave row contiguous
+ *                    in the row-major output, bytes r,g,b at 3*(row*ncols + col).
+ */
+#include "fr_kernels.h"
+
+#include "fr_math.h"
+
+namespace {
+
+__device__ const double g_log2_tab[FR_LOG2_N][3] = FR_LOG2_TABLE_INIT;
+
+constexpr int kWaves = 4; /* 256-thread workgroups */
+
+/* ---- colour map: calc/src/lib.rs:214-234 -------------------------------------------------- */
+
+struct ColourConsts {
+    double stable_limit, exposure;
+    double iterations_f64; /* config.iterations as f64 */
+    double inv_iterations; /* exact reciprocal when iterations is a power of two, else 0 */
+    uint32_t inside, smooth;
+    double prim[3], sec[3]; /* stored r, g, b fields as f64 */
+};
+
+__device__ __forceinline__ ColourConsts make_colour_consts(const fr_kparams &p) {
+    ColourConsts c;
+    c.stable_limit = p.stable_limit;
+    c.exposure = p.exposure;
+    c.iterations_f64 = (double)p.iterations;
+    const uint32_t n = p.iterations;
+    /* x / 2^k == x * 2^-k for every x (one exact real quotient, rounded once either way) */
+    c.inv_iterations = (n != 0 && (n & (n - 1)) == 0) ? 1.0 / (double)n : 0.0;
+    c.inside = p.inside;
+    c.smooth = p.smooth;
+    for (int k = 0; k < 3; k++) {
+        c.prim[k] = (double)p.prim[k];
+        c.sec[k] = (double)p.sec[k];
+    }
+    return c;
+}
+
+/* color_multiply (calc/src/lib.rs:133-139): RGB::new(r*m, g*m, b*m) with new's (r, b, g)
+ * parameter order, i.e. stored {r: r*m, g: b*m, b: g*m}; bytes are emitted r, g, b. */
+__device__ __forceinline__ void colour_multiply(const double col[3], double mult, uint8_t out[3]) {
+    out[0] = fr_sat_u8(col[0] * mult);
+    out[1] = fr_sat_u8(col[2] * mult);
+    out[2] = fr_sat_u8(col[1] * mult);
+}
+
+__device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, uint32_t iters_u,
+                                          const double *lds_tab, uint8_t out[3]) {
+    if (dist > c.stable_limit) { /* :216 */
+        double iters = (double)iters_u;
+        if (c.smooth) {
+            double log_zn = fr_log2_tab(__builtin_sqrt(dist), lds_tab) * 0.5; /* :222, x/2.0 == x*0.5 */
+            double nu = fr_log2_tab(log_zn, lds_tab);                         /* :223 */
+            iters += 1.0 - nu;                                                /* :225 */
+        }
+        double q = (c.inv_iterations != 0.0) ? iters * c.inv_iterations : iters / c.iterations_f64;
+        double mult = q * c.exposure; /* :228 */
+        colour_multiply(c.prim, mult, out);
+    } else if (c.inside) {
+        colour_multiply(c.sec, dist, out); /* :231 */
+    } else {
+        out[0] = out[1] = out[2] = 0; /* :233 */
+    }
+}
+
+/* ---- orbit loop: calc/src/lib.rs:245-257 --------------------------------------------------- */
+
+/* Runs recursive() for one lane.  On return (re, im) is the position recursive() returns (`next`
+ * on escape, `previous` on exhaustion — the same registers, updated in place), r2 = re*re and
+ * i2 = im*im of that position, and the result is the escape index.
+ *
+ * Per iteration, exactly the reference's roundings:
+ *   square():            (re*re) - (im*im)          |  (2.0*re)*im
+ *   + c:                 ... + c.re                 |  ... + c.im
+ *   squared_distance():  re'*re' + im'*im'    (re'*re' and im'*im' are reused by the next square()) */
+template <typename T>
+__device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
+                                          T &r2, T &i2) {
+    r2 = re * re;
+    i2 = im * im;
+    uint32_t it = iterations;
+    for (uint32_t i = 0; i < iterations; i++) {
+        T nre = (r2 - i2) + cre;
+        T nim = (((T)2 * re) * im) + cim;
+        re = nre;
+        im = nim;
+        r2 = re * re;
+        i2 = im * im;
+        T dist = r2 + i2;
+        if (dist > squared) {
+            it = i;
+            break;
+        }
+    }
+    return it;
+}
+
+/* coord_to_space — calc/src/lib.rs:182-184 */
+__device__ __forceinline__ double coord_to_space(double coord, double max, double offset, double pos,
+                                                 double scale) {
+    return ((coord / max) - offset) / scale + pos;
+}
+
+template <typename T, int TW, int TH, int WX, int WY, int MODE>
+__global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p, const fr_kout out) {
+    static_assert(TW * TH == 64 && WX * WY == kWaves, "one lane per pixel, 4 waves per workgroup");
+    constexpr int BW = TW * WX, BH = TH * WY;
+    __shared__ double s_tab[FR_LOG2_N * 3];
+    __shared__ double s_re[BW];
+    __shared__ double s_im[BH];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tiles_x = (p.ncols + BW - 1) / BW;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t col0 = bx * BW, row0 = by * BH;
+
+    /* stage the log2 table (3 KB) and this tile's coordinates in LDS */
+    if (MODE == FR_OUT_RGB) {
+        const double *gt = &g_log2_tab[0][0];
+        for (uint32_t k = tid; k < FR_LOG2_N * 3; k += 64 * kWaves) s_tab[k] = gt[k];
+    }
+    if (tid < BW + BH) {
+        const double width = (double)p.width, height = (double)p.height;
+        if (tid < BW) {
+            const uint32_t x = p.x_first + (col0 + tid) * p.x_stride;
+            s_re[tid] = coord_to_space((double)x, height, (width / height) / 2.0, p.pos_re, p.scale_re);
+        } else {
+            const uint32_t r = row0 + (tid - BW);
+            const uint32_t y = p.y_first + (r / p.block_rows) * p.y_stride + r % p.block_rows;
+            s_im[tid - BW] = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t lx = (wave % WX) * TW + lane % TW;
+    const uint32_t ly = (wave / WX) * TH + lane / TW;
+    const uint32_t cx = col0 + lx, r = row0 + ly;
+    const bool valid = cx < p.ncols && r < p.nrows;
+
+    const double sre = s_re[lx], sim = s_im[ly];
+    double zre = 0.0, zim = 0.0, dist = 0.0;
+    uint32_t iters = 0;
+    const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
+    if (valid && escape_algo) {
+        const double cre = p.algo == 0 ? sre : p.julia_re; /* calc/src/lib.rs:209-210 */
+        const double cim = p.algo == 0 ? sim : p.julia_im;
+        if constexpr (sizeof(T) == 8) {
+            double r2, i2;
+            zre = sre;
+            zim = sim;
+            iters = orbit<double>(p.iterations, zre, zim, cre, cim, p.limit * p.limit, r2, i2);
+            dist = r2 + i2; /* pos.squared_distance(), :214 */
+        } else {
+            float fre = (float)sre, fim = (float)sim, r2, i2;
+            const float lim = (float)p.limit;
+            iters = orbit<float>(p.iterations, fre, fim, (float)cre, (float)cim, lim * lim, r2, i2);
+            zre = (double)fre;
+            zim = (double)fim;
+            dist = zre * zre + zim * zim;
+        }
+    }
+
+    if constexpr (MODE == FR_OUT_RGB) {
+        if (valid) {
+            uint8_t rgb[3] = {0, 0, 0};
+            if (escape_algo) {
+                const ColourConsts cc = make_colour_consts(p);
+                colour_of(cc, dist, iters, s_tab, rgb);
+            }
+            uint8_t *o = out.rgb + 3ull * ((uint64_t)r * p.ncols + cx);
+            o[0] = rgb[0];
+            o[1] = rgb[1];
+            o[2] = rgb[2];
+        }
+    } else if constexpr (MODE == FR_OUT_ESCAPE) {
+        if (valid) {
+            const uint64_t k = (uint64_t)r * p.ncols + cx;
+            if (out.z) {
+                out.z[2 * k] = zre;
+                out.z[2 * k + 1] = zim;
+            }
+            if (out.iters) out.iters[k] = iters;
+        }
+    } else {
+        unsigned long long n = 0;
+        if (valid && escape_algo) n = iters < p.iterations ? (unsigned long long)iters + 1ull : p.iterations;
+        for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+        if (lane == 0 && n) atomicAdd(out.count, n);
+    }
+}
+
+template <typename T, int TW, int TH, int WX, int WY>
+hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStream_t stream) {
+    constexpr int BW = TW * WX, BH = TH * WY;
+    const uint64_t tiles_x = ((uint64_t)p.ncols + BW - 1) / BW;
+    const uint64_t tiles_y = ((uint64_t)p.nrows + BH - 1) / BH;
+    const uint64_t blocks = tiles_x * tiles_y;
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    dim3 grid((uint32_t)blocks), block(64 * kWaves);
+    switch (mode) {
+    case FR_OUT_RGB:
+        hipLaunchKernelGGL((escape_kernel<T, TW, TH, WX, WY, FR_OUT_RGB>), grid, block, 0, stream, p, out);
+        break;
+    case FR_OUT_ESCAPE:
+        hipLaunchKernelGGL((escape_kernel<T, TW, TH, WX, WY, FR_OUT_ESCAPE>), grid, block, 0, stream, p, out);
+        break;
+    default:
+        hipLaunchKernelGGL((escape_kernel<T, TW, TH, WX, WY, FR_OUT_COUNT>), grid, block, 0, stream, p, out);
+        break;
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream) {
+    switch (tile) {
+    case 6401:
+        return launch_tile<T, 64, 1, 1, 4>(p, mode, out, stream);
+    case 3202:
+        return launch_tile<T, 32, 2, 2, 2>(p, mode, out, stream);
+    case 1604:
+        return launch_tile<T, 16, 4, 2, 2>(p, mode, out, stream);
+    case 808:
+    case 0:
+        return launch_tile<T, 8, 8, 2, 2>(p, mode, out, stream);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
+/* ---- recursive() for arbitrary (start, c) pairs — calc/src/lib.rs:245-257 ------------------ */
+
+template <typename T>
+__global__ __launch_bounds__(256) void recursive_batch_kernel(uint32_t iterations, const double *start,
+                                                             const double *c, size_t n, double limit,
+                                                             double *out_pos, uint32_t *out_iters) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    T re = (T)start[2 * k], im = (T)start[2 * k + 1], r2, i2;
+    const T lim = (T)limit;
+    const uint32_t it = orbit<T>(iterations, re, im, (T)c[2 * k], (T)c[2 * k + 1], lim * lim, r2, i2);
+    out_pos[2 * k] = (double)re;
+    out_pos[2 * k + 1] = (double)im;
+    out_iters[k] = it;
+}
+
+__global__ __launch_bounds__(256) void math_probe_kernel(int which, const double *in, double *out, size_t n) {
+    __shared__ double s_tab[FR_LOG2_N * 3];
+    const double *gt = &g_log2_tab[0][0];
+    for (uint32_t k = threadIdx.x; k < FR_LOG2_N * 3; k += 256) s_tab[k] = gt[k];
+    __syncthreads();
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double x = in[k];
+    double y;
+    if (which == 0)
+        y = fr_log2_tab(x, s_tab);
+    else if (which == 1)
+        y = __builtin_sqrt(x);
+    else
+        y = x / in[(k + 1) % n];
+    out[k] = y;
+}
+
+} /* namespace */
+
+hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
+                            hipStream_t stream) {
+    if (precision == 1) return launch_precision<float>(p, mode, out, tile, stream);
+    return launch_precision<double>(p, mode, out, tile, stream);
+}
+
+hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, const double *c, size_t n,
+                                     double limit, int precision, double *out_pos, uint32_t *out_iters,
+                                     hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    if (precision == 1)
+        hipLaunchKernelGGL(recursive_batch_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, stream, iterations,
+                           start, c, n, limit, out_pos, out_iters);
+    else
+        hipLaunchKernelGGL(recursive_batch_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, stream, iterations,
+                           start, c, n, limit, out_pos, out_iters);
+    return hipGetLastError();
+}
+
+hipError_t fr_launch_math_probe(int which, const double *in, double *out, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(math_probe_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, which, in, out, n);
+    return hipGetLastError();
+}

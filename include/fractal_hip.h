@@ -1,0 +1,188 @@
+/*
+ * fractal_hip.h — C ABI of libfractal_hip.so, the MI355X (gfx950) implementation of
+ * Icelk/fractal-renderer's escape-time hot path.
+ *
+ * The reference is pure Rust and has NO FFI of its own; the seam this library fills is the
+ * three public functions + four types of the `calc` crate and the host library's get_image:
+ *
+ *   pub fn recursive(iterations, start, c, limit) -> (Imaginary, u32)   calc/src/lib.rs:245
+ *   pub fn get_recursive_pixel(&Config, x, y) -> RGB                    calc/src/lib.rs:199
+ *   pub fn get_image(&Config) -> Vec<RGB>   (Mandelbrot | Julia arm)    src/lib.rs:253-270
+ *   Config / Imaginary / RGB / Algo                                     calc/src/lib.rs:21-37,79-82,121-125,150-154
+ *
+ * Every entry point below names the reference interface it replaces.  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the patch to src/lib.rs:253-270 a maintainer would add.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  The CALLER owns every buffer; the library never frees or
+ *     keeps a caller pointer past the call.
+ *   - Every function returns FR_OK (0) or an fr_status error code and never aborts the process;
+ *     fr_last_error() returns a thread-local message for the last failing call on this thread.
+ *     (The reference's get_image is infallible; the Rust shim maps an error to a panic or to its
+ *     own CPU arm — INTEGRATION.md.)
+ *   - Re-entrant: may be called concurrently from several host threads with different configs,
+ *     as the GUI's render thread and screenshot thread do (src/gui.rs:56-60, 322-326).
+ *   - Output pixel layout is the reference's Vec<RGB>: row-major, tightly packed bytes r,g,b;
+ *     pixel (x, y) of the image lives at byte 3*(y*width + x).
+ *   - There is no CPU fallback: without a usable gfx950 device every compute call fails with
+ *     FR_ERR_NO_DEVICE.
+ */
+#ifndef FRACTAL_HIP_H
+#define FRACTAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_ABI_VERSION 1
+
+typedef enum fr_status {
+    FR_OK = 0,
+    FR_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, y0 > y1, y1 > height, ... */
+    FR_ERR_BUFFER_TOO_SMALL = 2, /* out_len < bytes the call must write */
+    FR_ERR_NO_DEVICE = 3,        /* no HIP device / not initialised and auto-init failed */
+    FR_ERR_HIP = 4,              /* a HIP runtime call failed; see fr_last_error() */
+    FR_ERR_UNSUPPORTED_ALGO = 5  /* reserved; Algo::BarnsleyFern is NOT an error (renders black) */
+} fr_status;
+
+/* enum Algo — calc/src/lib.rs:150-154, in declaration order */
+typedef enum fr_algo {
+    FR_ALGO_MANDELBROT = 0,
+    FR_ALGO_BARNSLEY_FERN = 1, /* on this path: every pixel RGB::BLACK (calc/src/lib.rs:211) */
+    FR_ALGO_JULIA = 2
+} fr_algo;
+
+/* struct Imaginary — calc/src/lib.rs:79-82 */
+typedef struct fr_imaginary {
+    double re;
+    double im;
+} fr_imaginary;
+
+/* struct RGB — calc/src/lib.rs:121-125.  These are the STORED fields.  RGB::new(r, b, g) takes
+ * blue second (calc/src/lib.rs:129-131), so e.g. Config::new's RGB::new(40, 40, 255) is stored
+ * {r:40, g:255, b:40}; pass the stored struct verbatim — the library reproduces color_multiply's
+ * swap (calc/src/lib.rs:133-139) internally. */
+typedef struct fr_rgb {
+    uint8_t r;
+    uint8_t g;
+    uint8_t b;
+} fr_rgb;
+
+/* struct Config — calc/src/lib.rs:21-37, field for field (`#[repr(C)]` image; bools as u8,
+ * enum as u32).  sizeof == 104. */
+typedef struct fr_config {
+    uint32_t algo; /* fr_algo */
+    uint32_t width;
+    uint32_t height;
+    uint32_t iterations;
+    double limit;        /* escape RADIUS; squared inside recursive() (calc/src/lib.rs:246) */
+    double stable_limit; /* compared with the SQUARED distance, un-squared (calc/src/lib.rs:216) */
+    fr_imaginary pos;
+    fr_imaginary scale; /* per-axis pair, not a complex number */
+    double exposure;
+    uint8_t inside;
+    uint8_t smooth;
+    fr_rgb primary_color;
+    fr_rgb secondary_color;
+    double color_weight; /* fern only; ignored on this path */
+    fr_imaginary julia_set;
+} fr_config;
+
+/* Arithmetic of the z = z^2 + c loop.  F64 is the reference's (and the only one with a parity
+ * claim against it).  F32 is this build's fast path for shallow zooms, defined as: coordinates
+ * (calc/src/lib.rs:181-197) in f64, start / c / limit narrowed to f32, recursive() evaluated in
+ * f32 with the same operation order, final position widened to f64, colour mapping in f64. */
+typedef enum fr_precision { FR_PRECISION_F64 = 0, FR_PRECISION_F32 = 1 } fr_precision;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* Select the HIP device this process renders on (-1 = keep the current one / device 0) and
+ * create the library's state.  Optional: compute calls auto-initialise on device 0. */
+int fr_init(int device);
+/* Release streams and scratch memory.  Safe to call twice; the library can be re-initialised. */
+int fr_shutdown(void);
+int fr_device_count(int *count);
+/* gfx architecture name of the active device, e.g. "gfx950:sramecc+:xnack-" */
+int fr_device_name(char *buf, size_t buf_len);
+const char *fr_last_error(void);
+int fr_abi_version(void);
+
+/* Config::new(algo) — calc/src/lib.rs:39-69 */
+void fr_config_new(fr_config *cfg, uint32_t algo);
+
+/* ---- get_image — src/lib.rs:253-270 ------------------------------------------------------- */
+
+/* Whole image into a HOST buffer of at least 3*width*height bytes (f64 arithmetic).
+ * Replaces `get_image(config)` for Algo::Mandelbrot | Algo::Julia. */
+int fr_render_rgb8(const fr_config *cfg, uint8_t *out, size_t out_len);
+
+/* Rows [y0, y1) of the image into a HOST buffer of at least 3*width*(y1-y0) bytes: the unit the
+ * reference's rayon loop parallelises over (src/lib.rs:256-264).  y0 == y1 is legal (no-op). */
+int fr_render_rows_rgb8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out,
+                        size_t out_len);
+
+/* Same, into DEVICE memory, asynchronously on `hip_stream` (a hipStream_t, NULL = the null
+ * stream).  For callers that keep the image in HBM (multi-GPU gather, GUI upload). */
+int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1,
+                               void *d_out, size_t out_len, void *hip_stream);
+
+/* Row-block-cyclic share of the image for multi-GPU rendering: blocks of `block_rows` rows,
+ * this call renders blocks first_block, first_block + block_stride, ... and packs them
+ * contiguously into d_out (device memory).  *rows_written (may be NULL) receives the number of
+ * rows produced.  fr_block_cyclic_rows() returns that count without rendering. */
+int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
+                                       uint32_t first_block, uint32_t block_stride, void *d_out,
+                                       size_t out_len, void *hip_stream, uint64_t *rows_written);
+uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t first_block,
+                              uint32_t block_stride);
+
+/* ---- get_recursive_pixel — calc/src/lib.rs:199-235 ---------------------------------------- */
+
+int fr_pixel(const fr_config *cfg, uint32_t x, uint32_t y, fr_rgb *out);
+int fr_pixel_p(const fr_config *cfg, int precision, uint32_t x, uint32_t y, fr_rgb *out);
+
+/* ---- recursive — calc/src/lib.rs:245-257 --------------------------------------------------- */
+
+/* One orbit: returns the final position and the escape index (== iterations on exhaustion). */
+int fr_recursive(uint32_t iterations, fr_imaginary start, fr_imaginary c, double limit,
+                 fr_imaginary *out_pos, uint32_t *out_iters);
+
+/* n independent orbits (host arrays): start[k], c[k] -> out_pos[k], out_iters[k]. */
+int fr_recursive_batch(uint32_t iterations, const fr_imaginary *start, const fr_imaginary *c, size_t n,
+                       double limit, int precision, fr_imaginary *out_pos, uint32_t *out_iters);
+
+/* recursive() results of every pixel of rows [y0, y1) (host arrays, either may be NULL):
+ * z_re_im[2k], z_re_im[2k+1] = final position, iters[k] = escape index, k = (y-y0)*width + x. */
+int fr_escape_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, double *z_re_im,
+                   uint32_t *iters);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+/* Exact sum of EXECUTED loop iterations over the pixels (x, y) with x % sx == 0, y % sy == 0 of
+ * rows [y0, y1): a pixel that escapes at index i executed i+1, one that exhausts the cap executed
+ * `iterations`.  Computed on the device. */
+int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint32_t sx,
+                        uint32_t sy, uint64_t *total, uint64_t *pixels);
+
+/* When enabled, device-pointer renders record HIP events around the escape+colour kernel on the
+ * stream they are launched on; fr_last_kernel_ms() waits for that kernel and returns its
+ * duration.  State is per calling thread. */
+int fr_set_profiling(int enabled);
+int fr_last_kernel_ms(float *ms);
+
+/* Kernel-variant selector for tuning studies: tile = lanes_x * 100 + lanes_y of the per-wave
+ * pixel footprint (6401 = 64x1, 3202, 1604, 808); 0 restores the default. */
+int fr_set_tile(int tile);
+
+/* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
+ * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n] — so tests can compare
+ * the device's roundings with the host's. */
+int fr_debug_math(int which, const double *in, double *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRACTAL_HIP_H */

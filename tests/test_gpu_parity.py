@@ -1,0 +1,299 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bar: byte-exact colours, integer-exact escape indices, bit-exact final positions (f64), at the
+same precision and iteration cap as the CPU path.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fr():
+    import fractal_renderer_amd
+
+    assert fractal_renderer_amd.device_count() > 0, "no HIP device: the GPU tests need a real MI355X"
+    fractal_renderer_amd.init(0)
+    assert fractal_renderer_amd.device_name().startswith("gfx950")
+    return fractal_renderer_amd
+
+
+def to_fr(fr, ocfg):
+    return fr.Config.from_buffer_copy(bytes(ocfg))
+
+
+def same_f64(a, b):
+    """Bit-identical, except that any NaN matches any NaN: the sign/payload of a generated NaN is
+    the platform's (x86 SSE makes 0xFFF8.., gfx950 0x7FF8..) — in the reference too."""
+    a, b = np.asarray(a), np.asarray(b)
+    nan = np.isnan(a)
+    return a.shape == b.shape and np.array_equal(nan, np.isnan(b)) and np.array_equal(
+        a.view(np.uint64)[~nan], b.view(np.uint64)[~nan])
+
+
+def oracle_image(ocfg, prec=O.F64, soft=True, **kw):
+    O.set_log2_mode(O.LOG2_SOFT if soft else O.LOG2_LIBM)
+    try:
+        return O.get_image(ocfg, prec, **kw)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+
+
+# ---- device arithmetic the colour pass relies on -------------------------------------------
+
+
+def _debug_math(fr, which, x):
+    from fractal_renderer_amd import _native
+
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    _native.check(_native.load().fr_debug_math(which, x.ctypes.data, y.ctypes.data, x.size))
+    return y
+
+
+def test_device_sqrt_is_correctly_rounded(fr):
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        np.exp(rng.uniform(-700, 700, 400_000)),
+        rng.uniform(0, 4, 400_000),
+        rng.uniform(2.0 ** 32, 2.0 ** 64, 200_000),
+        (rng.integers(1, 2 ** 26, 200_000).astype(np.float64)) ** 2,          # perfect squares
+        np.nextafter((rng.integers(1, 2 ** 26, 200_000).astype(np.float64)) ** 2, np.inf),
+        np.array([0.0, -0.0, np.inf, 1.0, 2.0, 4.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308]),
+    ])
+    got = _debug_math(fr, 1, x)
+    assert np.array_equal(got.view(np.uint64), np.sqrt(x).view(np.uint64))
+
+
+def test_device_division_is_correctly_rounded(fr):
+    rng = np.random.default_rng(12)
+    x = np.concatenate([np.exp(rng.uniform(-300, 300, 500_000)) * rng.choice([-1.0, 1.0], 500_000),
+                        rng.integers(1, 70000, 500_000).astype(np.float64)])
+    got = _debug_math(fr, 2, x)
+    want = x / np.roll(x, -1)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_device_log2_equals_host_soft_log2_and_tracks_libm(fr):
+    rng = np.random.default_rng(13)
+    x = np.concatenate([
+        np.exp(rng.uniform(-700, 700, 100_000)), rng.uniform(0.5, 2, 100_000), 1 + rng.uniform(-0.04, 0.04, 100_000),
+        rng.uniform(8, 16, 100_000), rng.uniform(65536, 2.0 ** 32, 100_000),
+        np.array([0.0, -0.0, 1.0, 2.0, 0.5, np.inf, 5e-324, 1e-310, 65536.0, 0.96875, 1.03125]),
+    ])
+    got = _debug_math(fr, 0, x)
+    O.set_log2_mode(O.LOG2_SOFT)
+    soft = np.array([O.log2(v) for v in x.tolist()])
+    O.set_log2_mode(O.LOG2_LIBM)
+    assert np.array_equal(got.view(np.uint64), soft.view(np.uint64)), "device log2 != host build of the same source"
+    libm = np.log2(x)
+    fin = np.isfinite(libm)
+    ulp = np.abs(got[fin].view(np.int64) - libm[fin].view(np.int64))
+    assert ulp.max() <= 1
+    assert math.isnan(_debug_math(fr, 0, np.array([-1.0]))[0]) and math.isnan(_debug_math(fr, 0, np.array([np.nan]))[0])
+
+
+# ---- known answers through the reference-shaped API ------------------------
+
+
+def test_kat_recursive(fr):
+    pos, it = fr.recursive(50, (2, 0), (2, 0), 65536)
+    assert (tuple(pos), it) == ((2090918.0, 0.0), 3)
+    pos, it = fr.recursive(50, (2, 0), (2, 0), 2)
+    assert (tuple(pos), it) == ((6.0, 0.0), 0)
+    pos, it = fr.recursive(50, (-2, 0), (-2, 0), 65536)
+    assert (tuple(pos), it) == ((2.0, 0.0), 50)
+    assert fr.recursive(50, (-1, 0), (-1, 0), 65536)[1] == 50
+    pos, it = fr.recursive(51, (-1, 0), (-1, 0), 65536)
+    assert (tuple(pos), it) == ((0.0, 0.0), 51)
+    for n in (0, 1, 50):
+        pos, it = fr.recursive(n, (0, 0), (0, 0), 65536)
+        assert (tuple(pos), it) == ((0.0, 0.0), n)
+
+
+def test_kat_pixels_and_4x4_image(fr):
+    cfg = fr.Config.new()
+    cfg.width = cfg.height = 4
+    cfg.scale.re = cfg.scale.im = 0.25
+    assert fr.get_recursive_pixel(cfg, 0, 2) == (83, 83, 255)
+    assert fr.get_recursive_pixel(cfg, 1, 2) == (240, 170, 0)
+    img = fr.get_image(cfg)
+    want = [[(0, 0, 5), (1, 1, 8), (1, 1, 9), (0, 0, 6)],
+            [(1, 1, 12), (3, 3, 22), (240, 170, 0), (2, 2, 13)],
+            [(83, 83, 255), (240, 170, 0), (0, 0, 0), (2, 2, 18)],
+            [(1, 1, 12), (3, 3, 22), (240, 170, 0), (2, 2, 13)]]
+    assert [[tuple(p) for p in row] for row in img.tolist()] == want
+    cfg.smooth = 0
+    img = fr.get_image(cfg)
+    want = [[(4, 4, 30)] * 4,
+            [(6, 6, 40), (8, 8, 51), (240, 170, 0), (6, 6, 40)],
+            [(80, 80, 255), (240, 170, 0), (0, 0, 0), (6, 6, 40)],
+            [(6, 6, 40), (8, 8, 51), (240, 170, 0), (6, 6, 40)]]
+    assert [[tuple(p) for p in row] for row in img.tolist()] == want
+    assert fr.get_recursive_pixel(cfg, 0, 2) == (80, 80, 255)
+
+
+def test_recursive_batch_matches_oracle(fr):
+    rng = np.random.default_rng(5)
+    n = 5000
+    start = rng.uniform(-2, 2, (n, 2))
+    c = np.where(rng.random((n, 1)) < 0.5, start, rng.uniform(-1, 1, (n, 2)))
+    for prec, f32 in ((fr.Precision.F64, False), (fr.Precision.F32, True)):
+        for limit in (65536.0, 2.0):
+            pos, it = fr.recursive_batch(300, start, c, limit, prec)
+            for k in range(0, n, 7):
+                wpos, wit = O.recursive(300, tuple(start[k]), tuple(c[k]), limit, f32=f32)
+                assert it[k] == wit and tuple(pos[k]) == wpos, (k, prec, limit)
+
+
+# ---- golden vectors ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("key", G.KEYS)
+def test_golden_vectors(fr, key):
+    ocfg = G.oracle_config(key)
+    cfg = to_fr(fr, ocfg)
+    prec = fr.Precision.F32 if G.precision_of(key) == O.F32 else fr.Precision.F64
+    v = G.vectors()
+    z, it = fr.escape_rows(cfg, precision=prec)
+    assert np.array_equal(it, v[key + "/iters"])
+    if key + "/z" in v.files:
+        assert same_f64(z, v[key + "/z"])
+    img = fr.get_image(cfg, prec)
+    assert np.array_equal(img, v[key + "/rgb"])
+    total, npx = fr.count_iterations(cfg, precision=prec)
+    assert total == G.MANIFEST[key]["executed_iterations"] and npx == cfg.width * cfg.height
+
+
+@pytest.mark.parametrize("tile", [6401, 3202, 1604, 808])
+def test_every_tile_shape_gives_the_same_bytes(fr, tile):
+    from fractal_renderer_amd import _native
+
+    v = G.vectors()
+    try:
+        _native.check(_native.load().fr_set_tile(tile))
+        for key in ("mandelbrot_default/257x193/f64", "julia_m08_0156/257x193/f32", "limit_2/257x193/f64"):
+            cfg = to_fr(fr, G.oracle_config(key))
+            prec = fr.Precision.F32 if key.endswith("f32") else fr.Precision.F64
+            assert np.array_equal(fr.get_image(cfg, prec), v[key + "/rgb"]), (tile, key)
+            assert fr.count_iterations(cfg, precision=prec)[0] == G.MANIFEST[key]["executed_iterations"]
+    finally:
+        _native.load().fr_set_tile(0)
+
+
+# ---- shapes, ranges, edge cases ----------------------------------------------------------------
+
+
+def test_row_ranges_and_empty_inputs(fr):
+    ocfg = G.oracle_config("mandelbrot_default/257x193/f64")
+    cfg = to_fr(fr, ocfg)
+    full = G.vectors()["mandelbrot_default/257x193/f64/rgb"]
+    parts = [fr.get_image_rows(cfg, a, b) for a, b in ((0, 1), (1, 100), (100, 193))]
+    assert np.array_equal(np.concatenate(parts), full)
+    assert fr.get_image_rows(cfg, 7, 7).shape == (0, 257, 3)
+    cfg.height = 0
+    assert fr.get_image(cfg).shape == (0, 257, 3)
+    cfg.height, cfg.width = 5, 0
+    assert fr.get_image(cfg).shape == (5, 0, 3)
+    with pytest.raises(fr.FractalHipError):
+        fr.get_image_rows(cfg, 3, 9)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 300), (300, 1), (63, 65), (1025, 7), (17, 1031)])
+def test_ragged_sizes(fr, w, h):
+    ocfg = O.cli_config(w, h, iterations=120)
+    cfg = to_fr(fr, ocfg)
+    assert np.array_equal(fr.get_image(cfg), oracle_image(ocfg))
+    z, it = fr.escape_rows(cfg)
+    wz, wit = O.escape_rows(ocfg)
+    assert np.array_equal(it, wit) and same_f64(z, wz)
+
+
+def test_get_recursive_pixel_outside_the_image(fr):
+    # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
+    ocfg = O.cli_config(64, 48, iterations=80)
+    cfg = to_fr(fr, ocfg)
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        for (x, y) in [(0, 0), (63, 47), (64, 48), (1000, 3), (5, 4000), (4294967295, 4294967295)]:
+            assert tuple(fr.get_recursive_pixel(cfg, x, y)) == O.get_recursive_pixel(ocfg, x, y), (x, y)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+
+
+BASELINE_VIEWS = {
+    "C2_default": dict(iterations=1024),
+    "C1_C3_zoom_1e6": dict(iterations=1024, scale=(1e6, 1e6), pos=(-0.7436447860, 0.1318252536)),
+    "C4_julia": dict(algo=O.JULIA, julia_set=(-0.8, 0.156), iterations=4096),
+}
+
+
+@pytest.mark.parametrize("view", sorted(BASELINE_VIEWS))
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_baseline_views_1024_crop(fr, view, prec):
+    """1024x1024 renders of each BASELINE.md view, all bytes against the oracle in both log2 modes."""
+    kw = dict(BASELINE_VIEWS[view])
+    algo = kw.pop("algo", O.MANDELBROT)
+    ocfg = O.cli_config(1024, 1024, algo, **kw)
+    cfg = to_fr(fr, ocfg)
+    op = O.F32 if prec == "f32" else O.F64
+    fp = fr.Precision.F32 if prec == "f32" else fr.Precision.F64
+    img = fr.get_image(cfg, fp)
+    assert np.array_equal(img, oracle_image(ocfg, op, soft=True))
+    assert np.array_equal(img, oracle_image(ocfg, op, soft=False))
+    assert fr.count_iterations(cfg, precision=fp)[0] == O.count_iterations(ocfg, op)
+
+
+def test_concurrent_callers(fr):
+    """src/gui.rs:56-60 + 322-326: the render thread and the screenshot thread call get_image
+    at the same time with different sizes."""
+    import threading
+
+    ocfgs = [O.cli_config(375, 250, iterations=200), O.cli_config(750, 500, iterations=200)]
+    want = [oracle_image(c) for c in ocfgs]
+    errs = []
+
+    def work(i):
+        try:
+            cfg = to_fr(fr, ocfgs[i])
+            for _ in range(5):
+                if not np.array_equal(fr.get_image(cfg), want[i]):
+                    errs.append("mismatch in thread %d" % i)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in (0, 1, 0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+
+
+# ---- BASELINE.json full sizes: size-independent properties + strided comparison ---------------
+
+
+def test_full_size_c2_sampled_against_oracle(fr):
+    """C2 (16384^2, 1024 iterations): every 16th pixel in x and y, colours and executed-iteration
+    sum, against the oracle; plus row-split invariance of the full image."""
+    ocfg = O.cli_config(16384, 16384, iterations=1024)
+    cfg = to_fr(fr, ocfg)
+    img = fr.get_image(cfg)
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        total, npx, want = O.sample_image(ocfg, 16, 16)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+    assert np.array_equal(img[::16, ::16], want)
+    assert fr.count_iterations(cfg, sx=16, sy=16) == (total, npx)
+    # vertical symmetry of the default view about row 8192 (im(y) = -im(16384 - y) exactly and the
+    # iteration is conjugation-symmetric): rows 1..8191 mirror rows 16383..8193
+    assert np.array_equal(img[1:8192], img[16383:8192:-1])
+    # any row band rendered on its own equals the same rows of the full render
+    band = fr.get_image_rows(cfg, 8000, 8192)
+    assert np.array_equal(band, img[8000:8192])
