@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
+
+Metric: pixel-iterations/s: Σ over pixels of EXECUTED loop iterations ÷ time, the
+Σ being an exact integer counted on the device outside the timed region (and cross-checked against
+the CPU oracle on the sampled pixels of the cpu_baseline leg).
+
+Workload at N GPUs (weak scaling, per-GPU pixel count fixed at 16384² = BASELINE config C2):
+    Mandelbrot, default view (-x -0.6 -y 0 -s 0.4), max_iter 1024, fp64, image W = H = round(16384·√N)
+    (N=1: 16384², N=4: 32768², N=2/8: 23170² / 46341²), row-block-cyclic over the ranks.
+A step = one pass of the hot path over the whole image: every rank renders its row blocks into
+HBM (inputs are just the Config; outputs stay resident in HBM), and for N > 1 the finished rows
+are gathered on rank 0 over RCCL and put in image order (the path's one real exchange step,
+north_star: "final RCCL gather over xGMI").
+
+One JSON line on stdout (rank 0).  `roofline` prices the escape+colour kernel against the gfx950
+fp64 VECTOR peak (this path is neither HBM- nor MFMA-bound); `cpu_baseline` is the
+oracle's row-parallel driver timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters) and SURVEY.md §8d
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop(FMA) x 2.4 GHz
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+FLOPS_PER_ITERATION = 10  # as written in the reference: calc/src/lib.rs:88-89,95,103-104
+VALU_OPS_PER_ITERATION = 8  # after reusing re², im² (bit-safe); FMA is forbidden by bit-exactness
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=16384, help="per-GPU image edge (default: BASELINE C2)")
+    ap.add_argument("--iterations", type=int, default=1024)
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--view", choices=["default", "zoom1e6", "julia"], default="default")
+    ap.add_argument("--block-rows", type=int, default=64)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores available)")
+    return ap.parse_args()
+
+
+def make_config(fr, args, edge):
+    """CLI-default Config (src/lib.rs:34-226: limit 65536, stable_limit 2, exposure 5, inside,
+    smooth, default colours) for the chosen view."""
+    cfg = fr.Config.new(fr.Algo.Julia if args.view == "julia" else fr.Algo.Mandelbrot)
+    cfg.width = cfg.height = edge
+    cfg.iterations = args.iterations
+    cfg.exposure = 5.0
+    if args.view == "default":
+        cfg.pos.re, cfg.pos.im = -0.6, 0.0
+    elif args.view == "zoom1e6":
+        cfg.pos.re, cfg.pos.im = -0.7436447860, 0.1318252536
+        cfg.scale.re = cfg.scale.im = 1e6
+    else:
+        cfg.julia_set.re, cfg.julia_set.im = -0.8, 0.156
+    return cfg
+
+
+def cpu_baseline(cfg_bytes, precision, threads):
+    """Time the CPU oracle (test infrastructure, used here ONLY as the reported baseline) on every
+    2nd pixel in x and y of the same workload.  Returns (dict, sampled colours, sampled Σ)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    ocfg = O.Config.from_buffer_copy(cfg_bytes)
+    sx = sy = 2
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        t0 = time.perf_counter()
+        total, npx, colours = O.sample_image(ocfg, sx, sy, precision, threads)
+        dt = time.perf_counter() - t0
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    info = {
+        "value": total / dt,
+        "unit": "pixel-iterations/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "every 2nd pixel in x and y of the same image (%d pixels, %d pixel-iterations, %.2f s); "
+                  "oracle/fractal_oracle.c row-parallel driver, -O2 -ffp-contract=off" % (npx, total, dt),
+        "cpu_model": model,
+        "host_cores_online": os.cpu_count(),
+    }
+    return info, colours, total, (sx, sy)
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch  # first: the library then shares torch's HIP runtime
+    import torch.distributed as dist
+
+    import fractal_renderer_amd as fr
+    from fractal_renderer_amd import _native
+    from fractal_renderer_amd import partition as P
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    fr.init(local_rank)
+    lib = _native.load()
+    _native.check(lib.fr_set_tile(args.tile))
+    device = torch.device("cuda", local_rank)
+    prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
+
+    edge = int(round(args.size * math.sqrt(world)))
+    cfg = make_config(fr, args, edge)
+    row_bytes = 3 * cfg.width
+    B = args.block_rows
+    my_rows = P.local_rows(cfg.height, B, rank, world)
+    max_rows = P.local_rows(cfg.height, B, 0, world)
+    local = torch.empty(max(max_rows * row_bytes, 1), dtype=torch.uint8, device=device)
+    scratch = torch.empty(world * max_rows * row_bytes, dtype=torch.uint8, device=device) if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream(device)
+
+    kernel_ms = []
+    _native.check(lib.fr_set_profiling(1))
+
+    def step(record):
+        P.render_local_hip(cfg, prec, B, rank, world, local, stream.cuda_stream)
+        if record:
+            ms = C.c_float(0)
+            _native.check(lib.fr_last_kernel_ms(C.byref(ms)))  # waits for this launch only
+            kernel_ms.append(ms.value)
+        if world > 1:
+            return P.gather_to_root(local, cfg.height, row_bytes, B, rank, world, scratch=scratch)
+        return local
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    img = None
+    for _ in range(args.steps):
+        img = step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # exact Σ executed iterations of the whole image, counted on the device outside the timed region
+    y0 = cfg.height * rank // world
+    y1 = cfg.height * (rank + 1) // world
+    total, _ = fr.count_iterations(cfg, y0, y1, 1, 1, prec)
+    kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
+    my_px_it = None
+    if world > 1:
+        t = torch.tensor([total], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = int(t.item())
+        k = torch.tensor([kavg], dtype=torch.float64, device=device)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kavg = float(k.item())
+
+    if rank == 0:
+        pixels = cfg.width * cfg.height
+        rate = total * args.steps / dt
+        peak = FP32_VECTOR_PEAK_TFLOPS if args.precision == "f32" else FP64_VECTOR_PEAK_TFLOPS
+        # the dominant kernel: per launch it executes this rank's share of the pixel-iterations
+        launch_px_it = total / world
+        achieved = FLOPS_PER_ITERATION * launch_px_it / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                rec = json.load(f).get("%dx%d_i%d_%s_%s" % (cfg.width, cfg.height, cfg.iterations, args.precision, args.view))
+                if rec:
+                    traffic = rec["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        out = {
+            "metric": "pixel_iterations_per_sec",
+            "value": rate,
+            "unit": "pixel-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic (deterministic: the image is a pure function of the Config)",
+            "config": {
+                "workload": "mandelbrot %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (
+                    cfg.width, cfg.height, cfg.iterations, args.precision, args.view,
+                    "C2" if (world == 1 and args.size == 16384 and args.iterations == 1024 and args.view == "default"
+                             and args.precision == "f64") else "C2-shaped, weak-scaled" if args.view == "default" else "variant"),
+                "per_gpu_pixels": pixels // world,
+                "partition": "row-block-cyclic, %d-row blocks, %d ranks" % (B, world),
+                "exchange": "none" if world == 1 else "RCCL gather to rank 0 + block reorder, inside the timed step",
+            },
+            "mpixels_per_sec": pixels * args.steps / dt / 1e6,
+            "pixel_iterations_per_image": total,
+            "kernel_ms_avg": kavg,
+            "roofline": {
+                "bound": "valu_f64" if args.precision == "f64" else "valu_f32",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "traffic": traffic,
+                "kernel": "escape_kernel (fused coordinate map + orbit loop + colour map)",
+                "algorithmic_flops_per_launch": FLOPS_PER_ITERATION * launch_px_it,
+                "frac_of_attainable_no_fma": (VALU_OPS_PER_ITERATION * launch_px_it / (kavg * 1e-3)) / (peak / 2 * 1e12)
+                if kavg > 0 else 0.0,
+                "note": "fp64 VECTOR peak (no MFMA, not HBM: 3 B/pixel written once). FMA is forbidden by "
+                        "bit-exactness, so the attainable ceiling is peak/2 lane-ops/s at 8 VALU ops/iteration.",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+            info, colours, cpu_total, (sx, sy) = cpu_baseline(bytes(cfg), int(prec), threads)
+            # byte-compare the GPU image with the CPU path on the sampled pixels, same run
+            got = img[: cfg.height * row_bytes].view(cfg.height, cfg.width, 3)[::sy, ::sx].cpu().numpy()
+            gpu_total, _ = fr.count_iterations(cfg, 0, cfg.height, sx, sy, prec)
+            info["gpu_bytes_identical_on_sample"] = bool((got == colours).all())
+            info["gpu_iteration_sum_identical_on_sample"] = bool(gpu_total == cpu_total)
+            out["cpu_baseline"] = info
+            out["gpu_over_cpu"] = rate / info["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

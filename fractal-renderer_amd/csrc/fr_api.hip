@@ -317,6 +317,30 @@ int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint
     return render_device(p, precision, d_out, static_cast<hipStream_t>(hip_stream));
 }
 
+int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t block_rows, uint32_t first_block,
+                                uint32_t block_stride, uint8_t *out, size_t out_len, uint64_t *rows_written) {
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    if (block_rows == 0 || block_stride == 0)
+        return fail(FR_ERR_INVALID_ARGUMENT, "block_rows and block_stride must be > 0");
+    const uint64_t rows = fr_block_cyclic_rows(cfg->height, block_rows, first_block, block_stride);
+    if (rows_written) *rows_written = rows;
+    const size_t need = (size_t)3 * cfg->width * (size_t)rows;
+    if (need == 0) return check_precision(precision);
+    if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
+    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*rows");
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = ensure_locked();
+    if (rc != FR_OK) return rc;
+    rc = reserve_locked(g.rgb, need);
+    if (rc != FR_OK) return rc;
+    rc = fr_render_block_cyclic_rgb8_device(cfg, precision, block_rows, first_block, block_stride, g.rgb.ptr, need,
+                                            g.stream, nullptr);
+    if (rc != FR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, need, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return FR_OK;
+}
+
 int fr_render_rows_rgb8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out,
                         size_t out_len) {
     int rc = check_rows(cfg, y0, y1);

@@ -89,27 +89,100 @@ __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, ui
  * i2 = im*im of that position, and the result is the escape index.
  *
  * Per iteration, exactly the reference's roundings:
- *   square():            (re*re) - (im*im)          |  (2.0*re)*im
+ *   square():            (re*re) - (im*im)          |  (2.0*re)*im      (2.0*re as re+re: exact)
  *   + c:                 ... + c.re                 |  ... + c.im
- *   squared_distance():  re'*re' + im'*im'    (re'*re' and im'*im' are reused by the next square()) */
+ *   squared_distance():  re'*re' + im'*im'    (re'*re' and im'*im' are reused by the next square())
+ *
+ * The loop is hand-written gfx950 ISA because its cost IS the kernel's cost: every VALU
+ * instruction here issues at 4 cycles per wave on the 16-lane f64 datapath (32-bit integer ops
+ * too — measured, tools/ubench/valu_rates.hip), so the floor is 9 VALU instructions per iteration
+ * (8 arithmetic + 1 compare) and everything else must be scalar:
+ *   - v_cmpx_nlt writes EXEC directly: a lane that escapes drops out with its registers frozen
+ *     at `next`, which is what recursive() returns;
+ *   - the iteration counter lives in an SGPR; a lane's escape index is written (one masked
+ *     v_mov_b32) only on the iterations where EXEC actually changed, found with s_xor_b64 on the
+ *     scalar unit;
+ *   - the wave leaves the loop when EXEC == 0 (every lane escaped) or the counter hits the cap;
+ *   - unrolled x4 so the scalar loop control is amortised; the remainder runs first.
+ * EXEC is restored before the block ends, so the compiler's view of control flow is unchanged. */
+#define FR_ORBIT_STEP(SFX, TAG)                    \
+    "v_add_" SFX " %[t], %[r2], -%[i2]\n"          \
+    "v_add_" SFX " %[x], %[re], %[re]\n"           \
+    "v_add_" SFX " %[re], %[t], %[cre]\n"          \
+    "v_mul_" SFX " %[x], %[x], %[im]\n"            \
+    "v_add_" SFX " %[im], %[x], %[cim]\n"          \
+    "v_mul_" SFX " %[r2], %[re], %[re]\n"          \
+    "v_mul_" SFX " %[i2], %[im], %[im]\n"          \
+    "v_add_" SFX " %[t], %[r2], %[i2]\n"           \
+    "s_mov_b64 %[sprev], exec\n"                   \
+    "v_cmpx_nlt_" SFX " %[lim2], %[t]\n"           \
+    "s_xor_b64 %[sdiff], %[sprev], exec\n"         \
+    "s_cbranch_scc1 .Lrec" TAG "_%=\n"             \
+    ".Lcont" TAG "_%=:\n"
+
+#define FR_ORBIT_RECORD(TAG, OFFSET)               \
+    ".Lrec" TAG "_%=:\n"                           \
+    "s_add_u32 %[stmp], %[si], " OFFSET "\n"       \
+    "s_mov_b64 %[sprev], exec\n"                   \
+    "s_mov_b64 exec, %[sdiff]\n"                   \
+    "v_mov_b32 %[it], %[stmp]\n"                   \
+    "s_mov_b64 exec, %[sprev]\n"                   \
+    "s_cbranch_execnz .Lcont" TAG "_%=\n"          \
+    "s_branch .Ldone_%=\n"
+
+#define FR_ORBIT_ASM(SFX)                                                          \
+    "s_mov_b64 %[sorig], exec\n"                                                   \
+    "v_mov_b32 %[it], %[n]\n"                                                      \
+    "s_cbranch_execz .Ldone_%=\n"                                                  \
+    "s_mov_b32 %[si], 0\n"                                                         \
+    "s_and_b32 %[nrem], %[n], 3\n"                                                 \
+    "s_cbranch_scc0 .Lmainentry_%=\n"                                              \
+    ".Lrem_%=:\n" FR_ORBIT_STEP(SFX, "R")                                          \
+    "s_add_u32 %[si], %[si], 1\n"                                                  \
+    "s_cmp_lt_u32 %[si], %[nrem]\n"                                                \
+    "s_cbranch_scc1 .Lrem_%=\n"                                                    \
+    ".Lmainentry_%=:\n"                                                            \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    ".Lmain_%=:\n" FR_ORBIT_STEP(SFX, "A") FR_ORBIT_STEP(SFX, "B") FR_ORBIT_STEP(SFX, "C") FR_ORBIT_STEP(SFX, "D") \
+    "s_add_u32 %[si], %[si], 4\n"                                                  \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc1 .Lmain_%=\n"                                                   \
+    "s_branch .Ldone_%=\n"                                                         \
+    FR_ORBIT_RECORD("R", "0") FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1")  \
+    FR_ORBIT_RECORD("C", "2") FR_ORBIT_RECORD("D", "3")                            \
+    ".Ldone_%=:\n"                                                                 \
+    "s_mov_b64 exec, %[sorig]\n"
+
 template <typename T>
 __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
                                           T &r2, T &i2) {
     r2 = re * re;
     i2 = im * im;
-    uint32_t it = iterations;
-    for (uint32_t i = 0; i < iterations; i++) {
-        T nre = (r2 - i2) + cre;
-        T nim = (((T)2 * re) * im) + cim;
-        re = nre;
-        im = nim;
-        r2 = re * re;
-        i2 = im * im;
-        T dist = r2 + i2;
-        if (dist > squared) {
-            it = i;
-            break;
-        }
+    uint32_t it;
+    T t, x;
+    unsigned long long sorig, sprev, sdiff;
+    uint32_t si, stmp, nrem;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
+    if constexpr (sizeof(T) == 8) {
+        /* limit^2 is wave-uniform: pin it in an SGPR pair (v_cmpx's src0) */
+        const uint64_t sq_bits = fr_bits_of(squared);
+        const uint64_t lim2 = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)sq_bits) |
+                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sq_bits >> 32)) << 32);
+        asm volatile(FR_ORBIT_ASM("f64")
+                     : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t),
+                       [x] "=&v"(x), [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff),
+                       [si] "=&s"(si), [stmp] "=&s"(stmp), [nrem] "=&s"(nrem)
+                     : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n)
+                     : "vcc", "scc");
+    } else {
+        const uint32_t lim2 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, squared));
+        asm volatile(FR_ORBIT_ASM("f32")
+                     : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t),
+                       [x] "=&v"(x), [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff),
+                       [si] "=&s"(si), [stmp] "=&s"(stmp), [nrem] "=&s"(nrem)
+                     : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n)
+                     : "vcc", "scc");
     }
     return it;
 }

@@ -136,6 +136,9 @@ int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0,
 int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
                                        uint32_t first_block, uint32_t block_stride, void *d_out,
                                        size_t out_len, void *hip_stream, uint64_t *rows_written);
+/* Same share into a HOST buffer (packed blocks, 3*width*rows bytes). */
+int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t block_rows, uint32_t first_block,
+                                uint32_t block_stride, uint8_t *out, size_t out_len, uint64_t *rows_written);
 uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t first_block,
                               uint32_t block_stride);
 

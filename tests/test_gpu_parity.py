@@ -216,6 +216,30 @@ def test_ragged_sizes(fr, w, h):
     assert np.array_equal(it, wit) and same_f64(z, wz)
 
 
+@pytest.mark.parametrize("world,block_rows", [(2, 64), (3, 16), (8, 8), (4, 1)])
+def test_logical_block_cyclic_partitions_on_one_device(fr, world, block_rows):
+    """The multi-GPU partition rendered as `world` logical shares on ONE device and reassembled
+    must be byte-identical to the single render."""
+    import torch
+
+    from fractal_renderer_amd import _native
+    from fractal_renderer_amd import partition as P
+
+    ocfg = G.oracle_config("golden_fringe_i400/257x193/f64")
+    cfg = to_fr(fr, ocfg)
+    want = G.vectors()["golden_fringe_i400/257x193/f64/rgb"]
+    rb = 3 * cfg.width
+    max_rows = P.local_rows(cfg.height, block_rows, 0, world)
+    gathered = np.zeros((world, max_rows * rb), dtype=np.uint8)
+    for r in range(world):
+        rows = C.c_uint64(0)
+        _native.check(_native.load().fr_render_block_cyclic_rgb8(
+            C.byref(cfg), 0, block_rows, r, world, gathered[r].ctypes.data, gathered[r].nbytes, C.byref(rows)))
+        assert rows.value == P.local_rows(cfg.height, block_rows, r, world)
+    img = P.assemble(torch.from_numpy(gathered), cfg.height, rb, block_rows, world).numpy()
+    assert np.array_equal(img.reshape(cfg.height, cfg.width, 3), want)
+
+
 def test_get_recursive_pixel_outside_the_image(fr):
     # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
     ocfg = O.cli_config(64, 48, iterations=80)
