@@ -121,6 +121,7 @@ PROTOTYPES = {
     "fr_set_profiling": (C.c_int, [C.c_int]),
     "fr_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "fr_set_tile": (C.c_int, [C.c_int]),
+    "fr_set_loop_mode": (C.c_int, [C.c_int]),
     "fr_debug_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 

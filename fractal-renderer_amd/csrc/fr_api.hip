@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -50,6 +51,7 @@ struct State {
 };
 State g;
 std::atomic<int> g_tile{0};
+std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 
 int fail(int code, const char *what) {
     tl_error = what;
@@ -153,6 +155,74 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.y_stride = 1;
 }
 
+/* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
+ * (the kernels compute every coordinate themselves). */
+double host_coord(double coord, double max, double offset, double pos, double scale) {
+    return ((coord / max) - offset) / scale + pos;
+}
+
+/* Choose the orbit-loop plan for a launch whose local grid is already set in `p`
+ * (see fr_kernels.hip, "orbit loop, scaled form", for what the kernel does with it and why it is
+ * exact).  loop_mode = M in {4, 2} and skip_t = T such that
+ *     dist_k <= T  and  every |c| component <= Cmax   =>   dist_{k+1..k+M-1} <= limit^2,
+ * using dist' <= g(dist) = 2 * (dist + Cmax)^2 * (1 + slack); T is found by inverting g M-1 times
+ * from limit^2.  Falls back to the unscaled loop (0) whenever the bound is useless or any
+ * parameter is outside the range the scaled form is proven for. */
+void plan_loop(const fr_config *cfg, int precision, fr_kparams &p) {
+    p.loop_mode = 0;
+    p.skip_t = 0.0;
+    const int forced = g_loop_mode.load();
+    if (forced == 0) return;
+    if (cfg->algo != FR_ALGO_MANDELBROT && cfg->algo != FR_ALGO_JULIA) return;
+    if (p.ncols == 0 || p.nrows == 0) return;
+    const bool f32 = precision == FR_PRECISION_F32;
+    const double range_hi = f32 ? 0x1p30 : 0x1p400;
+    const double slack = f32 ? 1.0 + 0x1p-18 : 1.0 + 0x1p-30;
+    if (!(std::fabs(cfg->limit) <= range_hi)) return; /* also rejects NaN */
+    double lim2;
+    if (f32) {
+        const float lf = (float)cfg->limit;
+        lim2 = (double)(lf * lf);
+    } else {
+        lim2 = cfg->limit * cfg->limit;
+    }
+    auto mag = [f32](double v) { return std::fabs(f32 ? (double)(float)v : v); };
+    double cmax;
+    if (cfg->algo == FR_ALGO_JULIA) {
+        cmax = std::fmax(mag(cfg->julia_set.re), mag(cfg->julia_set.im));
+    } else {
+        /* c = pixel coordinate; the map is monotone in x and in y, so the extremes are at the ends */
+        const double w = (double)cfg->width, h = (double)cfg->height;
+        const uint64_t x_last = (uint64_t)p.x_first + (uint64_t)(p.ncols - 1) * p.x_stride;
+        const uint32_t r_last = p.nrows - 1;
+        const uint64_t y_last = (uint64_t)p.y_first + (uint64_t)(r_last / p.block_rows) * p.y_stride + r_last % p.block_rows;
+        if (x_last > 0xFFFFFFFFull || y_last > 0xFFFFFFFFull) return;
+        cmax = 0.0;
+        for (double x : {(double)p.x_first, (double)x_last})
+            cmax = std::fmax(cmax, mag(host_coord(x, h, (w / h) / 2.0, cfg->pos.re, cfg->scale.re)));
+        for (double y : {(double)p.y_first, (double)y_last})
+            cmax = std::fmax(cmax, mag(host_coord(y, h, 0.5, cfg->pos.im, cfg->scale.im)));
+    }
+    if (!(cmax <= range_hi)) return; /* NaN / inf / huge */
+    for (int m : {4, 2}) {
+        if (forced > 0 && forced != m) continue;
+        double d = lim2;
+        for (int j = 1; j < m && d > 0.0; j++) d = std::sqrt(d / (2.0 * slack)) - cmax;
+        double t = d * (1.0 - 0x1p-20);
+        if (f32) { /* the kernel compares in f32: round T toward zero */
+            float tf = (float)t;
+            if ((double)tf > t) tf = std::nextafterf(tf, 0.0f);
+            t = (double)tf;
+        }
+        /* points of the set keep |z|^2 <= 4; below that the fast path would hardly ever run */
+        if (t >= 4.5 || (forced == m && t > 0.0)) {
+            p.loop_mode = (uint32_t)m;
+            p.skip_t = t;
+            return;
+        }
+    }
+}
+
 int check_rows(const fr_config *cfg, uint32_t y0, uint32_t y1) {
     if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
     if (y0 > y1) return fail(FR_ERR_INVALID_ARGUMENT, "y0 > y1");
@@ -167,7 +237,8 @@ int check_precision(int precision) {
 }
 
 /* device-pointer render of an arbitrary local grid; no locking, no global scratch: re-entrant */
-int render_device(const fr_kparams &p, int precision, void *d_out, hipStream_t stream) {
+int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_out, hipStream_t stream) {
+    plan_loop(cfg, precision, p);
     fr_kout out{};
     out.rgb = static_cast<uint8_t *>(d_out);
     Profiling &pr = tl_prof;
@@ -278,7 +349,7 @@ int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0,
     p.y_first = y0;
     p.block_rows = p.nrows;
     p.y_stride = 0;
-    return render_device(p, precision, d_out, static_cast<hipStream_t>(hip_stream));
+    return render_device(cfg, p, precision, d_out, static_cast<hipStream_t>(hip_stream));
 }
 
 uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t first_block, uint32_t block_stride) {
@@ -314,7 +385,7 @@ int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint
     p.block_rows = block_rows;
     p.y_first = first_block * block_rows;
     p.y_stride = block_rows * block_stride;
-    return render_device(p, precision, d_out, static_cast<hipStream_t>(hip_stream));
+    return render_device(cfg, p, precision, d_out, static_cast<hipStream_t>(hip_stream));
 }
 
 int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t block_rows, uint32_t first_block,
@@ -383,6 +454,7 @@ int fr_pixel_p(const fr_config *cfg, int precision, uint32_t x, uint32_t y, fr_r
     p.nrows = 1;
     p.x_first = x;
     p.y_first = y;
+    plan_loop(cfg, precision, p);
     fr_kout o{};
     o.rgb = static_cast<uint8_t *>(g.misc.ptr);
     HIP_TRY(fr_launch_escape(p, precision, FR_OUT_RGB, o, g_tile.load(), g.stream));
@@ -449,6 +521,7 @@ int fr_escape_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1
     p.y_first = y0;
     p.block_rows = p.nrows;
     p.y_stride = 0;
+    plan_loop(cfg, precision, p);
     fr_kout o{};
     o.z = z_re_im ? static_cast<double *>(g.z.ptr) : nullptr;
     o.iters = iters ? static_cast<uint32_t *>(g.iters.ptr) : nullptr;
@@ -485,6 +558,7 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
     rc = reserve_locked(g.misc, 256);
     if (rc != FR_OK) return rc;
     HIP_TRY(hipMemsetAsync(g.misc.ptr, 0, sizeof(unsigned long long), g.stream));
+    plan_loop(cfg, precision, p);
     fr_kout o{};
     o.count = static_cast<unsigned long long *>(g.misc.ptr);
     HIP_TRY(fr_launch_escape(p, precision, FR_OUT_COUNT, o, g_tile.load(), g.stream));
@@ -521,6 +595,13 @@ int fr_set_tile(int tile) {
     default:
         return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 6401, 3202, 1604 or 808");
     }
+}
+
+int fr_set_loop_mode(int mode) {
+    if (mode != -1 && mode != 0 && mode != 2 && mode != 4)
+        return fail(FR_ERR_INVALID_ARGUMENT, "loop mode must be -1 (auto), 0, 2 or 4");
+    g_loop_mode.store(mode);
+    return FR_OK;
 }
 
 /* test hook (not part of the reference surface): elementwise device log2 (which=0), sqrt (1) or

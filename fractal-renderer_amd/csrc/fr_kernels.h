@@ -26,6 +26,11 @@ struct fr_kparams {
     uint32_t ncols, nrows;
     uint32_t x_first, x_stride;
     uint32_t block_rows, y_first, y_stride;
+    /* orbit-loop plan chosen by the host (fr_api.hip: plan_loop): 0 = unscaled loop, escape
+     * check every iteration; 4 / 2 = scaled loop, escape check every 4th / 2nd iteration while
+     * every live lane of the wave has |z|^2 <= skip_t (see fr_kernels.hip). */
+    uint32_t loop_mode;
+    double skip_t;
 };
 
 enum fr_out_mode {

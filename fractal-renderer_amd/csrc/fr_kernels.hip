@@ -167,8 +167,8 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     if constexpr (sizeof(T) == 8) {
         /* limit^2 is wave-uniform: pin it in an SGPR pair (v_cmpx's src0) */
         const uint64_t sq_bits = fr_bits_of(squared);
-        const uint64_t lim2 = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)sq_bits) |
-                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sq_bits >> 32)) << 32);
+        const uint64_t lim2 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sq_bits) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sq_bits >> 32)) << 32);
         asm volatile(FR_ORBIT_ASM("f64")
                      : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t),
                        [x] "=&v"(x), [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff),
@@ -185,6 +185,189 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
                      : "vcc", "scc");
     }
     return it;
+}
+
+/* ---- orbit loop, scaled form ------------------------------------------------------------------
+ *
+ * Same recursion, carried as X = 2*re, Y = 2*im, A = X*X (= 4*re*re), B = Y*Y (= 4*im*im):
+ *
+ *     t4 = A - B                  = 4 * fl(re*re - im*im)
+ *     q  = X * Y                  = 2 * fl((2*re)*im)
+ *     X' = fma(t4, 0.5, 2*c.re)   = 2 * fl(fl(re*re - im*im) + c.re)     <- t4*0.5 is exact, so the
+ *     Y' = q + 2*c.im             = 2 * fl(fl((2*re)*im) + c.im)            fma rounds ONCE, exactly
+ *     A' = X'*X',  B' = Y'*Y'                                               where the reference does
+ *
+ * 6 VALU instructions instead of 8: the doubling folds into the state and the exact-by-
+ * construction fma replaces an add.  Scaling by 2 or 4 commutes with IEEE rounding as long as no
+ * intermediate is subnormal or overflows; lane_is_scalable() below admits only lanes for which
+ * that is provable (every |c| and start component in [2^-300, 2^400], f32: [2^-30, 2^30]: then
+ * every iterate is 0 or >= 2^-353 in magnitude, so no product is subnormal), and the host admits
+ * only limit <= 2^400 (f32: 2^30).  Any wave with an inadmissible lane runs the unscaled loop.
+ *
+ * Escape checks are skipped where they are provably false.  If dist_k = fl(re^2 + im^2) <= T and
+ * every |c| component <= Cmax, then dist_{k+1} <= g(T) = 2*(T + Cmax)^2 * (1 + 2^-30) (each of
+ * |re'|, |im'| <= (T + Cmax)(1 + few ulp)).  The host picks M in {4, 2} and the largest T with
+ * g^(M-1)(T) <= limit^2, so after a check `dist <= T` the next M-1 iterations cannot escape and
+ * need neither the distance add nor the compare; the M-th iteration is checked against T
+ * (v_cmp, no EXEC write) and, only if some lane exceeds T, exactly against limit^2 (v_cmpx).
+ * A wave with a lane above T ("in transit") runs M fully-checked iterations at a time until all
+ * its live lanes are back under T.  The fast block is M*6 + 2 VALU instructions. */
+#define FR_SC_IT(SFX)                              \
+    "v_add_" SFX " %[t], %[A], -%[B]\n"            \
+    "v_mul_" SFX " %[q], %[X], %[Y]\n"             \
+    "v_fma_" SFX " %[X], %[t], 0.5, %[c2re]\n"     \
+    "v_add_" SFX " %[Y], %[q], %[c2im]\n"          \
+    "v_mul_" SFX " %[A], %[X], %[X]\n"             \
+    "v_mul_" SFX " %[B], %[Y], %[Y]\n"
+
+#define FR_SC_CHECKED_STEP(SFX, TAG)               \
+    FR_SC_IT(SFX)                                  \
+    "v_add_" SFX " %[t], %[A], %[B]\n"             \
+    "s_mov_b64 %[sprev], exec\n"                   \
+    "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"           \
+    "s_xor_b64 %[sdiff], %[sprev], exec\n"         \
+    "s_cbranch_scc1 .Lrec" TAG "_%=\n"             \
+    ".Lcont" TAG "_%=:\n"
+
+#define FR_SC_ASM(SFX, MSTR, FAST_ITS, SLOW_STEPS, SLOW_RECORDS)                   \
+    "s_mov_b64 %[sorig], exec\n"                                                   \
+    "v_mov_b32 %[it], %[n]\n"                                                      \
+    "s_cbranch_execz .Ldone_%=\n"                                                  \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                                             \
+    "s_mov_b32 %[si], 0\n"                                                         \
+    "s_and_b32 %[nrem], %[n], " MSTR "-1\n"                                        \
+    "s_cbranch_scc0 .Lmodesel_%=\n"                                                \
+    ".Lrem_%=:\n" FR_SC_CHECKED_STEP(SFX, "R")                                     \
+    "s_add_u32 %[si], %[si], 1\n"                                                  \
+    "s_cmp_lt_u32 %[si], %[nrem]\n"                                                \
+    "s_cbranch_scc1 .Lrem_%=\n"                                                    \
+    ".Lmodesel_%=:\n"                                                              \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"                                       \
+    "s_cbranch_vccnz .Lslow_%=\n"                                                  \
+    ".Lfast_%=:\n" FAST_ITS                                                        \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                                             \
+    "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"                                       \
+    "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
+    "s_cbranch_vccnz .Lfastexit_%=\n"                                              \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc1 .Lfast_%=\n"                                                   \
+    "s_branch .Ldone_%=\n"                                                         \
+    ".Lfastexit_%=:\n"                                                             \
+    "s_mov_b64 %[sprev], exec\n"                                                   \
+    "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"                                           \
+    "s_xor_b64 %[sdiff], %[sprev], exec\n"                                         \
+    "s_cbranch_scc0 .Lfxnorec_%=\n"                                                \
+    "s_sub_u32 %[stmp], %[si], 1\n"                                                \
+    "s_mov_b64 %[sprev], exec\n"                                                   \
+    "s_mov_b64 exec, %[sdiff]\n"                                                   \
+    "v_mov_b32 %[it], %[stmp]\n"                                                   \
+    "s_mov_b64 exec, %[sprev]\n"                                                   \
+    "s_cbranch_execz .Ldone_%=\n"                                                  \
+    ".Lfxnorec_%=:\n"                                                              \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    ".Lslow_%=:\n" SLOW_STEPS                                                      \
+    "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"                                       \
+    "s_cbranch_vccz .Lfast_%=\n"                                                   \
+    "s_branch .Lslow_%=\n"                                                         \
+    FR_ORBIT_RECORD("R", "0") SLOW_RECORDS                                         \
+    ".Ldone_%=:\n"                                                                 \
+    "s_mov_b64 exec, %[sorig]\n"
+
+#define FR_SC_ASM_M4(SFX)                                                                          \
+    FR_SC_ASM(SFX, "4", FR_SC_IT(SFX) FR_SC_IT(SFX) FR_SC_IT(SFX) FR_SC_IT(SFX),                    \
+              FR_SC_CHECKED_STEP(SFX, "A") FR_SC_CHECKED_STEP(SFX, "B") FR_SC_CHECKED_STEP(SFX, "C") \
+                  FR_SC_CHECKED_STEP(SFX, "D"),                                                     \
+              FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1") FR_ORBIT_RECORD("C", "2")         \
+                  FR_ORBIT_RECORD("D", "3"))
+#define FR_SC_ASM_M2(SFX)                                                                  \
+    FR_SC_ASM(SFX, "2", FR_SC_IT(SFX) FR_SC_IT(SFX),                                        \
+              FR_SC_CHECKED_STEP(SFX, "A") FR_SC_CHECKED_STEP(SFX, "B"),                    \
+              FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"))
+
+template <typename T>
+struct ScalableRange;
+template <>
+struct ScalableRange<double> {
+    static constexpr double lo = 0x1p-300, hi = 0x1p400;
+};
+template <>
+struct ScalableRange<float> {
+    static constexpr float lo = 0x1p-30f, hi = 0x1p30f;
+};
+
+/* may this lane run the scaled loop with bit-identical results?  (see the proof sketch above) */
+template <typename T>
+__device__ __forceinline__ bool lane_is_scalable(T re0, T im0, T cre, T cim) {
+    constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
+    auto c_ok = [=](T v) { return __builtin_fabs(v) >= lo && __builtin_fabs(v) <= hi; };
+    auto s_ok = [=](T v) { return v == (T)0 || c_ok(v); };
+    return c_ok(cre) && c_ok(cim) && s_ok(re0) && s_ok(im0);
+}
+
+/* M = 4 or 2.  Same contract as orbit(): (re, im) in/out, r2/i2 out, returns the escape index.
+ * `squared` = limit^2 (of T), `skip_t` = the host's threshold T on fl(re^2+im^2). */
+template <typename T, int M>
+__device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
+                                                 T skip_t, T &r2, T &i2) {
+    T X = re + re, Y = im + im, A = X * X, B = Y * Y;
+    const T c2re = cre + cre, c2im = cim + cim;
+    uint32_t it;
+    T t, q;
+    unsigned long long sorig, sprev, sdiff;
+    uint32_t si, stmp, nrem;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
+    const T lim4_v = (T)4 * squared, t4_v = (T)4 * skip_t;
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t lb = fr_bits_of(lim4_v), tb = fr_bits_of(t4_v);
+        const uint64_t lim4 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lb) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lb >> 32)) << 32);
+        const uint64_t t4lim = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)tb) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32);
+#define FR_SC_OPERANDS                                                                                          \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [it] "=&v"(it), [t] "=&v"(t), [q] "=&v"(q),           \
+      [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),     \
+      [nrem] "=&s"(nrem)                                                                                        \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n)                      \
+    : "vcc", "scc"
+        if constexpr (M == 4)
+            asm volatile(FR_SC_ASM_M4("f64") FR_SC_OPERANDS);
+        else
+            asm volatile(FR_SC_ASM_M2("f64") FR_SC_OPERANDS);
+    } else {
+        const uint32_t lim4 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, lim4_v));
+        const uint32_t t4lim = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, t4_v));
+        if constexpr (M == 4)
+            asm volatile(FR_SC_ASM_M4("f32") FR_SC_OPERANDS);
+        else
+            asm volatile(FR_SC_ASM_M2("f32") FR_SC_OPERANDS);
+    }
+    re = X * (T)0.5; /* exact */
+    im = Y * (T)0.5;
+    r2 = re * re; /* recomputed from the final position: the reference's own re*re, im*im */
+    i2 = im * im;
+    return it;
+}
+
+/* Dispatch for one lane of a wave whose active lanes all call this together: the scaled loop if
+ * the host allowed it (loop_mode 4 or 2) AND every active lane of the wave is admissible,
+ * otherwise the unscaled loop.  The choice is wave-uniform. */
+template <typename T>
+__device__ __forceinline__ uint32_t orbit_auto(uint32_t loop_mode, uint32_t iterations, T &re, T &im, T cre, T cim,
+                                               T squared, T skip_t, T &r2, T &i2) {
+    if (loop_mode != 0) {
+        const bool bad = !lane_is_scalable<T>(re, im, cre, cim);
+        if (__ballot(bad) == 0ull) {
+            if (loop_mode == 4) return orbit_scaled<T, 4>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
+            return orbit_scaled<T, 2>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
+        }
+    }
+    return orbit<T>(iterations, re, im, cre, cim, squared, r2, i2);
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 */
@@ -241,12 +424,12 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
             double r2, i2;
             zre = sre;
             zim = sim;
-            iters = orbit<double>(p.iterations, zre, zim, cre, cim, p.limit * p.limit, r2, i2);
+            iters = orbit_auto<double>(p.loop_mode, p.iterations, zre, zim, cre, cim, p.limit * p.limit, p.skip_t, r2, i2);
             dist = r2 + i2; /* pos.squared_distance(), :214 */
         } else {
             float fre = (float)sre, fim = (float)sim, r2, i2;
             const float lim = (float)p.limit;
-            iters = orbit<float>(p.iterations, fre, fim, (float)cre, (float)cim, lim * lim, r2, i2);
+            iters = orbit_auto<float>(p.loop_mode, p.iterations, fre, fim, (float)cre, (float)cim, lim * lim, (float)p.skip_t, r2, i2);
             zre = (double)fre;
             zim = (double)fim;
             dist = zre * zre + zim * zim;

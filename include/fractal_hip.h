@@ -180,6 +180,12 @@ int fr_last_kernel_ms(float *ms);
  * pixel footprint (6401 = 64x1, 3202, 1604, 808); 0 restores the default. */
 int fr_set_tile(int tile);
 
+/* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled
+ * loop with an escape check every iteration; 4 / 2 = the scaled loop that checks every 4th / 2nd
+ * iteration, used only where it is provably bit-identical (otherwise the call still falls back to
+ * 0).  Every mode produces the same bytes. */
+int fr_set_loop_mode(int mode);
+
 /* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
  * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n] — so tests can compare
  * the device's roundings with the host's. */

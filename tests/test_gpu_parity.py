@@ -188,6 +188,79 @@ def test_every_tile_shape_gives_the_same_bytes(fr, tile):
         _native.load().fr_set_tile(0)
 
 
+@pytest.mark.parametrize("mode", [-1, 0, 2, 4])
+def test_every_orbit_loop_gives_the_same_bytes(fr, mode):
+    """The scaled / check-skipping loops (fr_kernels.hip) against the golden vectors, forced on."""
+    from fractal_renderer_amd import _native
+
+    v = G.vectors()
+    keys = [k for k in G.KEYS if k.split("/")[1] == "64x64"] + [
+        "golden_fringe_i400/257x193/f64", "julia_m08_0156/257x193/f32", "deep_5e5/257x193/f64",
+        "c1_view_1e6/257x193/f64", "limit_2/257x193/f32"]
+    try:
+        _native.check(_native.load().fr_set_loop_mode(mode))
+        for key in keys:
+            cfg = to_fr(fr, G.oracle_config(key))
+            prec = fr.Precision.F32 if key.endswith("f32") else fr.Precision.F64
+            z, it = fr.escape_rows(cfg, precision=prec)
+            assert np.array_equal(it, v[key + "/iters"]), (mode, key)
+            if key + "/z" in v.files:
+                assert same_f64(z, v[key + "/z"]), (mode, key)
+            assert np.array_equal(fr.get_image(cfg, prec), v[key + "/rgb"]), (mode, key)
+    finally:
+        _native.load().fr_set_loop_mode(-1)
+
+
+@pytest.mark.parametrize("limit", [1000.5, 3.7, 77777.123, 2.0 ** 20 + 1.0, 1e9, 1e100, 0.9])
+@pytest.mark.parametrize("mode", [-1, 0, 4])
+def test_limits_with_nonzero_low_mantissa_bits(fr, limit, mode):
+    """limit^2 travels to the loop as a 64-bit scalar; every bit of it must arrive."""
+    from fractal_renderer_amd import _native
+
+    ocfg = O.cli_config(160, 96, iterations=150, limit=limit)
+    cfg = to_fr(fr, ocfg)
+    try:
+        _native.check(_native.load().fr_set_loop_mode(mode))
+        for op, fp in ((O.F64, fr.Precision.F64), (O.F32, fr.Precision.F32)):
+            if op == O.F32 and limit > 1e30:
+                continue  # (f32)limit^2 overflows to inf: nothing escapes; covered by huge_limit golden
+            z, it = fr.escape_rows(cfg, precision=fp)
+            wz, wit = O.escape_rows(ocfg, op)
+            assert np.array_equal(it, wit), (limit, mode, op)
+            assert same_f64(z, wz)
+            assert np.array_equal(fr.get_image(cfg, fp), oracle_image(ocfg, op))
+    finally:
+        _native.load().fr_set_loop_mode(-1)
+
+
+TINY_CASES = {
+    # orbits whose products pass through the subnormal range: the scaled loop must not be used
+    "julia_c_zero": dict(algo=O.JULIA, julia_set=(0.0, 0.0), iterations=40),
+    "julia_c_subnormal": dict(algo=O.JULIA, julia_set=(1e-310, -3e-320), iterations=40),
+    "julia_c_tiny": dict(algo=O.JULIA, julia_set=(1e-200, 1e-170), iterations=60),
+    "julia_c_real": dict(algo=O.JULIA, julia_set=(-1.0, 0.0), iterations=300),
+    "mandelbrot_tiny_offsets": dict(iterations=80, pos=(1e-300, -1e-305)),
+    "mandelbrot_zoom_at_origin": dict(iterations=60, pos=(0.0, 0.0), scale=(1e150, 1e150)),
+    "mandelbrot_zoom_at_origin_deeper": dict(iterations=30, pos=(0.0, 0.0), scale=(1e300, 1e300)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TINY_CASES))
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_tiny_and_subnormal_orbits(fr, name, prec):
+    kw = dict(TINY_CASES[name])
+    algo = kw.pop("algo", O.MANDELBROT)
+    ocfg = O.cli_config(96, 64, algo, **kw)
+    cfg = to_fr(fr, ocfg)
+    op = O.F32 if prec == "f32" else O.F64
+    fp = fr.Precision.F32 if prec == "f32" else fr.Precision.F64
+    z, it = fr.escape_rows(cfg, precision=fp)
+    wz, wit = O.escape_rows(ocfg, op)
+    assert np.array_equal(it, wit)
+    assert same_f64(z, wz)
+    assert np.array_equal(fr.get_image(cfg, fp), oracle_image(ocfg, op))
+
+
 # ---- shapes, ranges, edge cases ----------------------------------------------------------------
 
 
