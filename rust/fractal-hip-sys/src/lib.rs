@@ -1,0 +1,90 @@
+//! `extern "C"` bindings to libfractal_hip.so (include/fractal_hip.h) plus the safe wrappers the
+//! reference's `get_image` / `get_recursive_pixel` / `recursive` call sites need.
+//!
+//! The `#[repr(C)]` types are the C ABI's image of `calc::Config`, `calc::Imaginary` and
+//! `calc::RGB` (calc/src/lib.rs:21-37, 79-82, 121-125).  `calc::RGB` is `repr(Rust)` today although
+//! the reference already transmutes it to 3 packed bytes (src/lib.rs:13-15, src/gui.rs:62-64);
+//! adding `#[repr(C)]` to it makes that assumption sound and lets `Vec<RGB>` be filled in place.
+//!
+//! Untested in this pipeline (no rustc); kept mechanical on purpose.
+#![allow(non_camel_case_types)]
+
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub struct fr_imaginary {
+    pub re: f64,
+    pub im: f64,
+}
+
+/// The STORED fields of `calc::RGB` (not `RGB::new`'s `(r, b, g)` parameter order).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct fr_rgb {
+    pub r: u8,
+    pub g: u8,
+    pub b: u8,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct fr_config {
+    pub algo: u32, // 0 Mandelbrot, 1 BarnsleyFern, 2 Julia (calc/src/lib.rs:150-154)
+    pub width: u32,
+    pub height: u32,
+    pub iterations: u32,
+    pub limit: f64,
+    pub stable_limit: f64,
+    pub pos: fr_imaginary,
+    pub scale: fr_imaginary,
+    pub exposure: f64,
+    pub inside: u8,
+    pub smooth: u8,
+    pub primary_color: fr_rgb,
+    pub secondary_color: fr_rgb,
+    pub color_weight: f64,
+    pub julia_set: fr_imaginary,
+}
+
+pub const FR_OK: c_int = 0;
+pub const FR_PRECISION_F64: c_int = 0;
+pub const FR_PRECISION_F32: c_int = 1;
+
+extern "C" {
+    pub fn fr_init(device: c_int) -> c_int;
+    pub fn fr_shutdown() -> c_int;
+    pub fn fr_device_count(count: *mut c_int) -> c_int;
+    pub fn fr_last_error() -> *const c_char;
+    pub fn fr_config_new(cfg: *mut fr_config, algo: u32);
+    pub fn fr_render_rgb8(cfg: *const fr_config, out: *mut u8, out_len: usize) -> c_int;
+    pub fn fr_render_rows_rgb8(cfg: *const fr_config, precision: c_int, y0: u32, y1: u32, out: *mut u8, out_len: usize) -> c_int;
+    pub fn fr_render_rows_rgb8_device(cfg: *const fr_config, precision: c_int, y0: u32, y1: u32, d_out: *mut c_void, out_len: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn fr_pixel(cfg: *const fr_config, x: u32, y: u32, out: *mut fr_rgb) -> c_int;
+    pub fn fr_recursive(iterations: u32, start: fr_imaginary, c: fr_imaginary, limit: f64, out_pos: *mut fr_imaginary, out_iters: *mut u32) -> c_int;
+    pub fn fr_escape_rows(cfg: *const fr_config, precision: c_int, y0: u32, y1: u32, z_re_im: *mut f64, iters: *mut u32) -> c_int;
+}
+
+/// Message of the last failing call on this thread.
+pub fn last_error() -> String {
+    unsafe {
+        let p = fr_last_error();
+        if p.is_null() { String::new() } else { CStr::from_ptr(p).to_string_lossy().into_owned() }
+    }
+}
+
+/// `get_image` for `Algo::Mandelbrot | Algo::Julia` (src/lib.rs:253-270): fills a caller-owned
+/// pixel vector in place.  `P` must be a 3-byte `#[repr(C)]` pixel (`calc::RGB` once annotated).
+pub fn render_into<P: Copy>(cfg: &fr_config, image: &mut Vec<P>) -> Result<(), String> {
+    assert_eq!(std::mem::size_of::<P>(), 3, "pixel type must be 3 packed bytes");
+    let n = cfg.width as usize * cfg.height as usize;
+    image.clear();
+    image.reserve_exact(n);
+    let rc = unsafe { fr_render_rgb8(cfg, image.as_mut_ptr() as *mut u8, n * 3) };
+    if rc != FR_OK {
+        return Err(last_error());
+    }
+    unsafe { image.set_len(n) }; // every byte was written by the library
+    Ok(())
+}

@@ -1,0 +1,45 @@
+// What a maintainer would change in the reference (illustrative; not compiled here).
+//
+// calc/src/lib.rs:121 — make the layout the rest of the code already assumes explicit:
+//     #[repr(C)]
+//     pub struct RGB { pub r: u8, pub g: u8, pub b: u8 }
+//
+// src/lib.rs:253-270 — the Mandelbrot | Julia arm of get_image becomes one FFI call; the
+// BarnsleyFern arm (src/lib.rs:271-319) is untouched.
+
+fn to_ffi(config: &Config) -> fractal_hip_sys::fr_config {
+    use fractal_hip_sys::{fr_config, fr_imaginary, fr_rgb};
+    let im = |v: &Imaginary| fr_imaginary { re: v.re, im: v.im };
+    let rgb = |c: &RGB| fr_rgb { r: c.r, g: c.g, b: c.b }; // stored fields, verbatim
+    fr_config {
+        algo: match config.algo { Algo::Mandelbrot => 0, Algo::BarnsleyFern => 1, Algo::Julia => 2 },
+        width: config.width,
+        height: config.height,
+        iterations: config.iterations,
+        limit: config.limit,
+        stable_limit: config.stable_limit,
+        pos: im(&config.pos),
+        scale: im(&config.scale),
+        exposure: config.exposure,
+        inside: config.inside as u8,
+        smooth: config.smooth as u8,
+        primary_color: rgb(&config.primary_color),
+        secondary_color: rgb(&config.secondary_color),
+        color_weight: config.color_weight,
+        julia_set: im(&config.julia_set),
+    }
+}
+
+pub fn get_image(config: &Config) -> Vec<RGB> {
+    match config.algo {
+        Algo::Mandelbrot | Algo::Julia => {
+            let mut image: Vec<RGB> = Vec::new();
+            // get_image is infallible in the reference; a GPU failure is a panic here (or call the
+            // old rayon arm instead — the maintainer's choice).
+            fractal_hip_sys::render_into(&to_ffi(config), &mut image)
+                .unwrap_or_else(|e| panic!("fractal_hip: {}", e));
+            image
+        }
+        Algo::BarnsleyFern => { /* src/lib.rs:271-319 unchanged */ unimplemented!() }
+    }
+}
