@@ -394,3 +394,23 @@ def test_full_size_c2_sampled_against_oracle(fr):
     # any row band rendered on its own equals the same rows of the full render
     band = fr.get_image_rows(cfg, 8000, 8192)
     assert np.array_equal(band, img[8000:8192])
+
+
+def test_bench_smoke_small():
+    """bench.py end to end on a small image: torch-first import order, HIP-event timing, roofline and
+    cpu_baseline objects, and its own GPU-vs-CPU byte comparison."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "2048", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["metric"] == "pixel_iterations_per_sec" and d["n_gpus"] == 1 and d["value"] > 1e9
+    assert d["roofline"]["achieved"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["gpu_bytes_identical_on_sample"] is True
+    assert d["cpu_baseline"]["gpu_iteration_sum_identical_on_sample"] is True

@@ -24,18 +24,9 @@ def _free_port():
     return port
 
 
-def _oracle_render_fn(ocfg):
-    from fractal_renderer_amd import partition as P
-
-    def render(config, precision, block_rows, rank, world, out):
-        rows = P.local_rows(config.height, block_rows, rank, world)
-        buf = out[: rows * 3 * config.width].view(rows, config.width, 3).numpy()
-        lr = 0
-        while lr < rows:
-            y = P.global_row_of(lr, block_rows, rank, world)
-            n = min(block_rows, config.height - y)
-            buf[lr : lr + n] = O.get_image(ocfg, y0=y, y1=y + n, threads=1)
-            lr += n
+def _oracle_render_rows(ocfg):
+    def render(config, precision, y0, y1, out):
+        out.view(y1 - y0, config.width, 3).numpy()[:] = O.get_image(ocfg, y0=y0, y1=y1, threads=1)
 
     return render
 
@@ -52,17 +43,21 @@ def _worker(rank, world, port, w, h, block_rows, q):
 
         ocfg = O.cli_config(w, h, iterations=60)
         cfg = fr.Config.from_buffer_copy(bytes(ocfg))
-        img = P.render_distributed(cfg, 0, block_rows, render_fn=_oracle_render_fn(ocfg), device="cpu")
+        renderer = P.DistributedRenderer(cfg, 0, block_rows, render_rows=_oracle_render_rows(ocfg))
+        ok = True
+        for _ in range(2):  # buffers are reused across steps
+            img = renderer.render()
+            if rank == 0:
+                ok = ok and bool(np.array_equal(img.numpy(), O.get_image(ocfg, threads=1)))
+            else:
+                assert img is None
         if rank == 0:
-            want = O.get_image(ocfg, threads=1)
-            q.put(bool(np.array_equal(img.numpy(), want)))
-        else:
-            assert img is None
+            q.put(ok)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,w,h,block_rows", [(2, 33, 70, 8), (2, 16, 64, 8), (3, 20, 101, 16), (2, 9, 5, 8)])
+@pytest.mark.parametrize("world,w,h,block_rows", [(2, 33, 70, 8), (2, 16, 64, 8), (3, 20, 101, 16), (2, 9, 5, 8), (4, 12, 37, 4)])
 def test_block_cyclic_gather_reassembles_the_image(world, w, h, block_rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
