@@ -586,6 +586,10 @@ int fr_last_kernel_ms(float *ms) {
 int fr_set_tile(int tile) {
     switch (tile) {
     case 0:
+    case 1:
+    case 2:
+    case 4:
+    case 8:
     case 6401:
     case 3202:
     case 1604:
@@ -593,7 +597,7 @@ int fr_set_tile(int tile) {
         g_tile.store(tile);
         return FR_OK;
     default:
-        return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 6401, 3202, 1604 or 808");
+        return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 6401, 3202, 1604 or 808");
     }
 }
 

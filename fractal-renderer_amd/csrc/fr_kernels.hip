@@ -57,10 +57,21 @@ __device__ __forceinline__ ColourConsts make_colour_consts(const fr_kparams &p) 
 
 /* color_multiply (calc/src/lib.rs:133-139): RGB::new(r*m, g*m, b*m) with new's (r, b, g)
  * parameter order, i.e. stored {r: r*m, g: b*m, b: g*m}; bytes are emitted r, g, b. */
+/* Rust's `f64 as u8` (truncate, saturate, NaN -> 0) in two instructions: v_cvt_u32_f64 truncates
+ * toward zero, saturates out-of-range inputs (negative -> 0, huge / +inf -> 0xFFFFFFFF) and maps
+ * NaN to 0; the min brings it to u8 range.  (Inline asm because a plain C cast of an out-of-range
+ * value is undefined behaviour to the optimiser.)  Checked against the host's fr_sat_u8 by
+ * test_device_saturating_cast. */
+__device__ __forceinline__ uint32_t sat_u8_dev(double v) {
+    uint32_t u;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(u) : "v"(v));
+    return u < 255u ? u : 255u;
+}
+
 __device__ __forceinline__ void colour_multiply(const double col[3], double mult, uint8_t out[3]) {
-    out[0] = fr_sat_u8(col[0] * mult);
-    out[1] = fr_sat_u8(col[2] * mult);
-    out[2] = fr_sat_u8(col[1] * mult);
+    out[0] = (uint8_t)sat_u8_dev(col[0] * mult);
+    out[1] = (uint8_t)sat_u8_dev(col[2] * mult);
+    out[2] = (uint8_t)sat_u8_dev(col[1] * mult);
 }
 
 __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, uint32_t iters_u,
@@ -376,6 +387,66 @@ __device__ __forceinline__ double coord_to_space(double coord, double max, doubl
     return ((coord / max) - offset) / scale + pos;
 }
 
+/* One pixel per lane, from its start coordinate to its output: orbit loop, then the colour map
+ * (MODE RGB), the raw recursive() result (MODE ESCAPE) or the executed-iteration sum (MODE COUNT).
+ * Every lane of the wave calls this together; `valid` masks lanes that fall outside the image. */
+template <typename T, int MODE>
+__device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout &out, const double *s_tab,
+                                             double sre, double sim, bool valid, uint32_t cx, uint32_t r,
+                                             uint32_t lane) {
+    double zre = 0.0, zim = 0.0, dist = 0.0;
+    uint32_t iters = 0;
+    const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
+    if (valid && escape_algo) {
+        const double cre = p.algo == 0 ? sre : p.julia_re; /* calc/src/lib.rs:209-210 */
+        const double cim = p.algo == 0 ? sim : p.julia_im;
+        if constexpr (sizeof(T) == 8) {
+            double r2, i2;
+            zre = sre;
+            zim = sim;
+            iters = orbit_auto<double>(p.loop_mode, p.iterations, zre, zim, cre, cim, p.limit * p.limit, p.skip_t,
+                                       r2, i2);
+            dist = r2 + i2; /* pos.squared_distance(), :214 */
+        } else {
+            float fre = (float)sre, fim = (float)sim, r2, i2;
+            const float lim = (float)p.limit;
+            iters = orbit_auto<float>(p.loop_mode, p.iterations, fre, fim, (float)cre, (float)cim, lim * lim,
+                                      (float)p.skip_t, r2, i2);
+            zre = (double)fre;
+            zim = (double)fim;
+            dist = zre * zre + zim * zim;
+        }
+    }
+
+    if constexpr (MODE == FR_OUT_RGB) {
+        if (valid) {
+            uint8_t rgb[3] = {0, 0, 0};
+            if (escape_algo) {
+                const ColourConsts cc = make_colour_consts(p);
+                colour_of(cc, dist, iters, s_tab, rgb);
+            }
+            uint8_t *o = out.rgb + 3ull * ((uint64_t)r * p.ncols + cx);
+            o[0] = rgb[0];
+            o[1] = rgb[1];
+            o[2] = rgb[2];
+        }
+    } else if constexpr (MODE == FR_OUT_ESCAPE) {
+        if (valid) {
+            const uint64_t k = (uint64_t)r * p.ncols + cx;
+            if (out.z) {
+                out.z[2 * k] = zre;
+                out.z[2 * k + 1] = zim;
+            }
+            if (out.iters) out.iters[k] = iters;
+        }
+    } else {
+        unsigned long long n = 0;
+        if (valid && escape_algo) n = iters < p.iterations ? (unsigned long long)iters + 1ull : p.iterations;
+        for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+        if (lane == 0 && n) atomicAdd(out.count, n);
+    }
+}
+
 template <typename T, int TW, int TH, int WX, int WY, int MODE>
 __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p, const fr_kout out) {
     static_assert(TW * TH == 64 && WX * WY == kWaves, "one lane per pixel, 4 waves per workgroup");
@@ -412,57 +483,89 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
     const uint32_t ly = (wave / WX) * TH + lane / TW;
     const uint32_t cx = col0 + lx, r = row0 + ly;
     const bool valid = cx < p.ncols && r < p.nrows;
+    render_pixel<T, MODE>(p, out, s_tab, s_re[lx], s_im[ly], valid, cx, r, lane);
+}
 
-    const double sre = s_re[lx], sim = s_im[ly];
-    double zre = 0.0, zim = 0.0, dist = 0.0;
-    uint32_t iters = 0;
-    const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
-    if (valid && escape_algo) {
-        const double cre = p.algo == 0 ? sre : p.julia_re; /* calc/src/lib.rs:209-210 */
-        const double cim = p.algo == 0 ? sim : p.julia_im;
-        if constexpr (sizeof(T) == 8) {
-            double r2, i2;
-            zre = sre;
-            zim = sim;
-            iters = orbit_auto<double>(p.loop_mode, p.iterations, zre, zim, cre, cim, p.limit * p.limit, p.skip_t, r2, i2);
-            dist = r2 + i2; /* pos.squared_distance(), :214 */
-        } else {
-            float fre = (float)sre, fim = (float)sim, r2, i2;
-            const float lim = (float)p.limit;
-            iters = orbit_auto<float>(p.loop_mode, p.iterations, fre, fim, (float)cre, (float)cim, lim * lim, (float)p.skip_t, r2, i2);
-            zre = (double)fre;
-            zim = (double)fim;
-            dist = zre * zre + zim * zim;
-        }
-    }
+/* Default kernel: ONE WAVE PER WORKGROUP renders a horizontal strip of kStripTiles 8x8 tiles
+ * (64 x 8 pixels at 8 tiles), one tile at a time.
+ *
+ * Why: with one tile per wave, a workgroup's fixed costs — launch, staging the 3 KB log2 table,
+ * the barrier behind it — are paid once per 256 pixels, and outside the set (three quarters of the
+ * default view, ~20 iterations per pixel) they dominate.  Here they are paid once per strip and
+ * there is no barrier at all.  (Multi-wave workgroups with strips were measured and are WORSE the
+ * longer the strip: a CU does not backfill the slots of a workgroup's finished waves while one of
+ * its waves is still deep inside the set — 4 waves x 8 tiles ran C2 in 22.6 ms against 14.6 ms for
+ * 4 waves x 1 tile.  A one-wave workgroup has nothing to wait for.)
+ *   - the coordinate map (calc/src/lib.rs:181-197) of a tile is evaluated by 16 lanes of the wave
+ *     itself (lanes 0-7: the 8 column values, lanes 8-15: the 8 row values — re depends only on x,
+ *     im only on y) and distributed to the 64 lanes with two cross-lane reads (ds_bpermute), no LDS
+ *     storage and no barrier;
+ *   - there are still >> 256 workgroups (C2: 524 288) for the dispatcher to balance.
+ * The grid is 2-D/3-D, so no integer division is needed to find a tile. */
 
-    if constexpr (MODE == FR_OUT_RGB) {
-        if (valid) {
-            uint8_t rgb[3] = {0, 0, 0};
-            if (escape_algo) {
-                const ColourConsts cc = make_colour_consts(p);
-                colour_of(cc, dist, iters, s_tab, rgb);
-            }
-            uint8_t *o = out.rgb + 3ull * ((uint64_t)r * p.ncols + cx);
-            o[0] = rgb[0];
-            o[1] = rgb[1];
-            o[2] = rgb[2];
-        }
-    } else if constexpr (MODE == FR_OUT_ESCAPE) {
-        if (valid) {
-            const uint64_t k = (uint64_t)r * p.ncols + cx;
-            if (out.z) {
-                out.z[2 * k] = zre;
-                out.z[2 * k + 1] = zim;
-            }
-            if (out.iters) out.iters[k] = iters;
-        }
-    } else {
-        unsigned long long n = 0;
-        if (valid && escape_algo) n = iters < p.iterations ? (unsigned long long)iters + 1ull : p.iterations;
-        for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
-        if (lane == 0 && n) atomicAdd(out.count, n);
+template <typename T, int MODE, int kStripTiles>
+__global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, const fr_kout out) {
+    __shared__ double s_tab[FR_LOG2_N * 3];
+    const uint32_t tid = threadIdx.x;
+    if (MODE == FR_OUT_RGB) {
+        const double *gt = &g_log2_tab[0][0];
+        for (uint32_t k = tid; k < FR_LOG2_N * 3; k += 64) s_tab[k] = gt[k];
+        __syncthreads();
     }
+    const uint32_t lane = tid;
+    const uint32_t row0 = (blockIdx.y + gridDim.y * blockIdx.z) * 8u;
+    if (row0 >= p.nrows) return; /* whole workgroup (uniform) */
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t r = row0 + ly;
+    const double width = (double)p.width, height = (double)p.height;
+
+    /* lanes 8-15 hold this strip's 8 row coordinates for the whole loop */
+    double im_lane = 0.0;
+    if (lane >= 8 && lane < 16) {
+        const uint32_t rr = row0 + (lane - 8);
+        const uint32_t y = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
+        im_lane = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
+    }
+    const double sim = __shfl(im_lane, 8 + ly, 64);
+    const double x_offset = (width / height) / 2.0;
+
+    const uint32_t tile0 = blockIdx.x * kStripTiles;
+    for (int k = 0; k < kStripTiles; k++) {
+        const uint32_t col0 = (tile0 + k) * 8u;
+        if (col0 >= p.ncols) break; /* wave-uniform */
+        double re_lane = 0.0;
+        if (lane < 8) {
+            const uint32_t x = p.x_first + (col0 + lane) * p.x_stride;
+            re_lane = coord_to_space((double)x, height, x_offset, p.pos_re, p.scale_re);
+        }
+        const double sre = __shfl(re_lane, lx, 64);
+        const uint32_t cx = col0 + lx;
+        const bool valid = cx < p.ncols && r < p.nrows;
+        render_pixel<T, MODE>(p, out, s_tab, sre, sim, valid, cx, r, lane);
+    }
+}
+
+template <typename T, int kStripTiles>
+hipError_t launch_strips(const fr_kparams &p, int mode, const fr_kout &out, hipStream_t stream) {
+    if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
+    const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
+    const uint64_t row_tiles = ((uint64_t)p.nrows + 7) / 8;
+    const uint64_t gy = row_tiles < 32768 ? row_tiles : 32768;
+    const uint64_t gz = (row_tiles + gy - 1) / gy;
+    if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
+    dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz), block(64);
+    switch (mode) {
+    case FR_OUT_RGB:
+        hipLaunchKernelGGL((escape_strip_kernel<T, FR_OUT_RGB, kStripTiles>), grid, block, 0, stream, p, out);
+        break;
+    case FR_OUT_ESCAPE:
+        hipLaunchKernelGGL((escape_strip_kernel<T, FR_OUT_ESCAPE, kStripTiles>), grid, block, 0, stream, p, out);
+        break;
+    default:
+        hipLaunchKernelGGL((escape_strip_kernel<T, FR_OUT_COUNT, kStripTiles>), grid, block, 0, stream, p, out);
+        break;
+    }
+    return hipGetLastError();
 }
 
 template <typename T, int TW, int TH, int WX, int WY>
@@ -498,8 +601,23 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
     case 1604:
         return launch_tile<T, 16, 4, 2, 2>(p, mode, out, stream);
     case 808:
-    case 0:
         return launch_tile<T, 8, 8, 2, 2>(p, mode, out, stream);
+    case 0: {
+        /* strip length by image size: long strips amortise the per-workgroup setup, short ones
+         * keep every SIMD supplied with several waves when the image is small (GUI frames) */
+        const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
+        if (tiles >= 65536) return launch_strips<T, 4>(p, mode, out, stream);
+        if (tiles >= 16384) return launch_strips<T, 2>(p, mode, out, stream);
+        return launch_strips<T, 1>(p, mode, out, stream);
+    }
+    case 8:
+        return launch_strips<T, 8>(p, mode, out, stream);
+    case 1:
+        return launch_strips<T, 1>(p, mode, out, stream);
+    case 2:
+        return launch_strips<T, 2>(p, mode, out, stream);
+    case 4:
+        return launch_strips<T, 4>(p, mode, out, stream);
     default:
         return hipErrorInvalidValue;
     }
@@ -534,6 +652,8 @@ __global__ __launch_bounds__(256) void math_probe_kernel(int which, const double
         y = fr_log2_tab(x, s_tab);
     else if (which == 1)
         y = __builtin_sqrt(x);
+    else if (which == 3)
+        y = (double)sat_u8_dev(x);
     else
         y = x / in[(k + 1) % n];
     out[k] = y;

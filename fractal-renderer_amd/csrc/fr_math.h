@@ -28,10 +28,23 @@
 #define FR_HD static inline
 #endif
 
+#define FR_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+/* The polynomial coefficients.  On the host they are literals.  On the device they are read from
+ * mutable constant memory so that they arrive in SGPRs through scalar loads (a 64-bit literal
+ * cannot be a VALU operand on gfx950: as literals each one costs two v_mov_b32 per pixel, and the
+ * VALU issue rate is this kernel's bound).  Same values either way. */
 #if defined(__HIP_DEVICE_COMPILE__)
-#define FR_FMA(a, b, c) __builtin_fma((a), (b), (c))
+__constant__ double fr_log2_coef_dev[15] = {FR_INVLN2_HI, FR_INVLN2_LO, FR_LOG2_A2,  FR_LOG2_A3,  FR_LOG2_A4,
+                                            FR_LOG2_A5,   FR_LOG2_A6,   FR_LOG2_A7,  FR_LOG2_A8,  FR_LOG2_A9,
+                                            FR_LOG2_A10,  FR_LOG2_A11,  FR_LOG2_A12, FR_LOG2_A13, FR_LOG2_A14};
+#define FR_K_INVLN2_HI fr_log2_coef_dev[0]
+#define FR_K_INVLN2_LO fr_log2_coef_dev[1]
+#define FR_K_A(n) fr_log2_coef_dev[n]
 #else
-#define FR_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define FR_K_INVLN2_HI FR_INVLN2_HI
+#define FR_K_INVLN2_LO FR_INVLN2_LO
+#define FR_K_A(n) FR_LOG2_A##n
 #endif
 
 FR_HD uint64_t fr_bits_of(double x) {
@@ -77,22 +90,22 @@ FR_HD double fr_log2_tab(double x, const double *tab) {
     /* near 1: 1 - 2^-5 <= x < 1 + 2^-5 */
     if (ix - 0x3FEF000000000000ull < 0x3FF0800000000000ull - 0x3FEF000000000000ull) {
         double r = x - 1.0; /* exact (Sterbenz) */
-        double t1 = r * FR_INVLN2_HI;
-        double t2 = FR_FMA(r, FR_INVLN2_HI, -t1) + r * FR_INVLN2_LO;
+        double t1 = r * FR_K_INVLN2_HI;
+        double t2 = FR_FMA(r, FR_K_INVLN2_HI, -t1) + r * FR_K_INVLN2_LO;
         double r2 = r * r;
-        double p = FR_LOG2_A14;
-        p = FR_FMA(p, r, FR_LOG2_A13);
-        p = FR_FMA(p, r, FR_LOG2_A12);
-        p = FR_FMA(p, r, FR_LOG2_A11);
-        p = FR_FMA(p, r, FR_LOG2_A10);
-        p = FR_FMA(p, r, FR_LOG2_A9);
-        p = FR_FMA(p, r, FR_LOG2_A8);
-        p = FR_FMA(p, r, FR_LOG2_A7);
-        p = FR_FMA(p, r, FR_LOG2_A6);
-        p = FR_FMA(p, r, FR_LOG2_A5);
-        p = FR_FMA(p, r, FR_LOG2_A4);
-        p = FR_FMA(p, r, FR_LOG2_A3);
-        p = FR_FMA(p, r, FR_LOG2_A2);
+        double p = FR_K_A(14);
+        p = FR_FMA(p, r, FR_K_A(13));
+        p = FR_FMA(p, r, FR_K_A(12));
+        p = FR_FMA(p, r, FR_K_A(11));
+        p = FR_FMA(p, r, FR_K_A(10));
+        p = FR_FMA(p, r, FR_K_A(9));
+        p = FR_FMA(p, r, FR_K_A(8));
+        p = FR_FMA(p, r, FR_K_A(7));
+        p = FR_FMA(p, r, FR_K_A(6));
+        p = FR_FMA(p, r, FR_K_A(5));
+        p = FR_FMA(p, r, FR_K_A(4));
+        p = FR_FMA(p, r, FR_K_A(3));
+        p = FR_FMA(p, r, FR_K_A(2));
         p = p * r2;
         double hi = t1 + p;
         double lo = ((t1 - hi) + p) + t2; /* Fast2Sum: |t1| >= |p| */
@@ -122,18 +135,18 @@ FR_HD double fr_log2_tab(double x, const double *tab) {
 
     double r = FR_FMA(z, invc, -1.0);
     double t0 = kd + logc_hi; /* exact: logc_hi is a multiple of 2^-40, |k| < 2^11 */
-    double t1 = r * FR_INVLN2_HI;
-    double t2 = FR_FMA(r, FR_INVLN2_HI, -t1) + r * FR_INVLN2_LO;
+    double t1 = r * FR_K_INVLN2_HI;
+    double t2 = FR_FMA(r, FR_K_INVLN2_HI, -t1) + r * FR_K_INVLN2_LO;
     double hi = t0 + t1;
     double lo = ((t0 - hi) + t1) + (t2 + logc_lo); /* Fast2Sum: |t0| > |t1| outside the near-1 zone */
     double r2 = r * r;
-    double p = FR_LOG2_A8;
-    p = FR_FMA(p, r, FR_LOG2_A7);
-    p = FR_FMA(p, r, FR_LOG2_A6);
-    p = FR_FMA(p, r, FR_LOG2_A5);
-    p = FR_FMA(p, r, FR_LOG2_A4);
-    p = FR_FMA(p, r, FR_LOG2_A3);
-    p = FR_FMA(p, r, FR_LOG2_A2);
+    double p = FR_K_A(8);
+    p = FR_FMA(p, r, FR_K_A(7));
+    p = FR_FMA(p, r, FR_K_A(6));
+    p = FR_FMA(p, r, FR_K_A(5));
+    p = FR_FMA(p, r, FR_K_A(4));
+    p = FR_FMA(p, r, FR_K_A(3));
+    p = FR_FMA(p, r, FR_K_A(2));
     lo = FR_FMA(p, r2, lo);
     return hi + lo;
 }

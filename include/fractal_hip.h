@@ -176,8 +176,10 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
 int fr_set_profiling(int enabled);
 int fr_last_kernel_ms(float *ms);
 
-/* Kernel-variant selector for tuning studies: tile = lanes_x * 100 + lanes_y of the per-wave
- * pixel footprint (6401 = 64x1, 3202, 1604, 808); 0 restores the default. */
+/* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
+ * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
+ * 1, 2, 4, 8 = that kernel with a fixed strip length; 6401, 3202, 1604, 808 = the 4-wave-workgroup
+ * kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave pixel footprint. */
 int fr_set_tile(int tile);
 
 /* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled
@@ -187,7 +189,8 @@ int fr_set_tile(int tile);
 int fr_set_loop_mode(int mode);
 
 /* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
- * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n] — so tests can compare
+ * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n], 3: the `as u8` cast —
+ * so tests can compare
  * the device's roundings with the host's. */
 int fr_debug_math(int which, const double *in, double *out, size_t n);
 

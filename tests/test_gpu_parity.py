@@ -81,6 +81,19 @@ def test_device_division_is_correctly_rounded(fr):
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
+def test_device_saturating_cast(fr):
+    """Rust `f64 as u8` (calc/src/lib.rs:135-137): truncate toward zero, saturate, NaN -> 0."""
+    rng = np.random.default_rng(14)
+    x = np.concatenate([rng.uniform(-10, 300, 200_000), rng.uniform(0, 1, 1000), np.arange(0, 258, dtype=np.float64),
+                        np.nextafter(np.arange(0, 258, dtype=np.float64), -np.inf),
+                        np.array([np.nan, -np.nan, np.inf, -np.inf, 1e300, -1e300, 4294967295.0, 4294967296.0,
+                                  1e19, -0.0, 0.0, 0.9999999999999999, 254.99999999999997, 255.0, 5e-324, -5e-324])])
+    got = _debug_math(fr, 3, x)
+    with np.errstate(invalid="ignore"):
+        want = np.where(np.isnan(x), 0.0, np.clip(np.trunc(x), 0, 255))
+    assert np.array_equal(got, want)
+
+
 def test_device_log2_equals_host_soft_log2_and_tracks_libm(fr):
     rng = np.random.default_rng(13)
     x = np.concatenate([
@@ -172,14 +185,15 @@ def test_golden_vectors(fr, key):
     assert total == G.MANIFEST[key]["executed_iterations"] and npx == cfg.width * cfg.height
 
 
-@pytest.mark.parametrize("tile", [6401, 3202, 1604, 808])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 8, 6401, 3202, 1604, 808])
 def test_every_tile_shape_gives_the_same_bytes(fr, tile):
     from fractal_renderer_amd import _native
 
     v = G.vectors()
     try:
         _native.check(_native.load().fr_set_tile(tile))
-        for key in ("mandelbrot_default/257x193/f64", "julia_m08_0156/257x193/f32", "limit_2/257x193/f64"):
+        for key in ("mandelbrot_default/257x193/f64", "julia_m08_0156/257x193/f32", "limit_2/257x193/f64",
+                    "deep_5e5/64x64/f64", "unsmooth/257x193/f32"):
             cfg = to_fr(fr, G.oracle_config(key))
             prec = fr.Precision.F32 if key.endswith("f32") else fr.Precision.F64
             assert np.array_equal(fr.get_image(cfg, prec), v[key + "/rgb"]), (tile, key)
