@@ -122,6 +122,7 @@ PROTOTYPES = {
     "fr_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "fr_set_tile": (C.c_int, [C.c_int]),
     "fr_set_loop_mode": (C.c_int, [C.c_int]),
+    "fr_set_palette": (C.c_int, [C.c_int]),
     "fr_debug_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 

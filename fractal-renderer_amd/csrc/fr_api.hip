@@ -51,6 +51,7 @@ struct State {
 };
 State g;
 std::atomic<int> g_tile{0};
+std::atomic<int> g_palette_enabled{1};
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 
 int fail(int code, const char *what) {
@@ -239,6 +240,29 @@ int check_precision(int precision) {
 /* device-pointer render of an arbitrary local grid; no locking, no global scratch: re-entrant */
 int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_out, hipStream_t stream) {
     plan_loop(cfg, precision, p);
+    /* smooth == false: the outside colour is a function of the escape index alone, so build the
+     * (iterations + 1)-entry palette once (stream-ordered scratch) and let every workgroup stage it
+     * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
+    uint32_t *palette = nullptr;
+    const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
+    if (!cfg->smooth && escape_algo && g_palette_enabled.load() && cfg->iterations < FR_MAX_PALETTE_ENTRIES &&
+        g_tile.load() <= 8) {
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&palette), sizeof(uint32_t) * (cfg->iterations + 1), stream));
+        p.palette = palette;
+        p.palette_entries = cfg->iterations + 1;
+        hipError_t e = fr_launch_palette(p, palette, stream);
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(palette, stream);
+            return fail_hip(e, "fr_launch_palette");
+        }
+    }
+    struct PaletteGuard {
+        uint32_t *ptr;
+        hipStream_t stream;
+        ~PaletteGuard() {
+            if (ptr) (void)hipFreeAsync(ptr, stream); /* stream-ordered: after the render kernel */
+        }
+    } guard{palette, stream};
     fr_kout out{};
     out.rgb = static_cast<uint8_t *>(d_out);
     Profiling &pr = tl_prof;
@@ -599,6 +623,11 @@ int fr_set_tile(int tile) {
     default:
         return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 6401, 3202, 1604 or 808");
     }
+}
+
+int fr_set_palette(int enabled) {
+    g_palette_enabled.store(enabled ? 1 : 0);
+    return FR_OK;
 }
 
 int fr_set_loop_mode(int mode) {

@@ -31,6 +31,10 @@ struct fr_kparams {
      * every live lane of the wave has |z|^2 <= skip_t (see fr_kernels.hip). */
     uint32_t loop_mode;
     double skip_t;
+    /* smooth == false only: palette[i] = packed r | g << 8 | b << 16 of an OUTSIDE pixel whose
+     * escape index is i (0 .. iterations), built by fr_launch_palette; NULL = compute per pixel */
+    const uint32_t *palette;
+    uint32_t palette_entries;
 };
 
 enum fr_out_mode {
@@ -49,6 +53,13 @@ struct fr_kout {
 /* tile = lanes_x*100 + lanes_y of the per-wave footprint; 0 = default */
 hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
                             hipStream_t stream);
+
+/* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
+ * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */
+constexpr uint32_t FR_MAX_PALETTE_ENTRIES = 1280;
+
+/* palette[i], i = 0 .. p.iterations, for smooth == false (see fr_kparams::palette) */
+hipError_t fr_launch_palette(const fr_kparams &p, uint32_t *palette, hipStream_t stream);
 
 /* n independent orbits, device arrays (re, im interleaved) */
 hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, const double *c, size_t n,

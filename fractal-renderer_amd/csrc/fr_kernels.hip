@@ -74,18 +74,32 @@ __device__ __forceinline__ void colour_multiply(const double col[3], double mult
     out[2] = (uint8_t)sat_u8_dev(col[1] * mult);
 }
 
+/* outside colouring without the smooth term: a function of the escape index alone */
+__device__ __forceinline__ void colour_outside_flat(const ColourConsts &c, uint32_t iters_u, uint8_t out[3]) {
+    const double iters = (double)iters_u;
+    const double q = (c.inv_iterations != 0.0) ? iters * c.inv_iterations : iters / c.iterations_f64;
+    colour_multiply(c.prim, q * c.exposure, out); /* :228-229 */
+}
+
+/* `palette` (LDS) is non-NULL only when smooth == false: "LDS-staged palette lookup". */
 __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, uint32_t iters_u,
-                                          const double *lds_tab, uint8_t out[3]) {
+                                          const double *lds_tab, const uint32_t *palette, uint8_t out[3]) {
     if (dist > c.stable_limit) { /* :216 */
-        double iters = (double)iters_u;
-        if (c.smooth) {
+        if (palette) {
+            const uint32_t v = palette[iters_u];
+            out[0] = (uint8_t)v;
+            out[1] = (uint8_t)(v >> 8);
+            out[2] = (uint8_t)(v >> 16);
+        } else if (c.smooth) {
+            double iters = (double)iters_u;
             double log_zn = fr_log2_tab(__builtin_sqrt(dist), lds_tab) * 0.5; /* :222, x/2.0 == x*0.5 */
             double nu = fr_log2_tab(log_zn, lds_tab);                         /* :223 */
             iters += 1.0 - nu;                                                /* :225 */
+            double q = (c.inv_iterations != 0.0) ? iters * c.inv_iterations : iters / c.iterations_f64;
+            colour_multiply(c.prim, q * c.exposure, out); /* :228-229 */
+        } else {
+            colour_outside_flat(c, iters_u, out);
         }
-        double q = (c.inv_iterations != 0.0) ? iters * c.inv_iterations : iters / c.iterations_f64;
-        double mult = q * c.exposure; /* :228 */
-        colour_multiply(c.prim, mult, out);
     } else if (c.inside) {
         colour_multiply(c.sec, dist, out); /* :231 */
     } else {
@@ -392,8 +406,8 @@ __device__ __forceinline__ double coord_to_space(double coord, double max, doubl
  * Every lane of the wave calls this together; `valid` masks lanes that fall outside the image. */
 template <typename T, int MODE>
 __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout &out, const double *s_tab,
-                                             double sre, double sim, bool valid, uint32_t cx, uint32_t r,
-                                             uint32_t lane) {
+                                             const uint32_t *s_pal, double sre, double sim, bool valid,
+                                             uint32_t cx, uint32_t r, uint32_t lane) {
     double zre = 0.0, zim = 0.0, dist = 0.0;
     uint32_t iters = 0;
     const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
@@ -423,7 +437,7 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
             uint8_t rgb[3] = {0, 0, 0};
             if (escape_algo) {
                 const ColourConsts cc = make_colour_consts(p);
-                colour_of(cc, dist, iters, s_tab, rgb);
+                colour_of(cc, dist, iters, s_tab, s_pal, rgb);
             }
             uint8_t *o = out.rgb + 3ull * ((uint64_t)r * p.ncols + cx);
             o[0] = rgb[0];
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
     const uint32_t ly = (wave / WX) * TH + lane / TW;
     const uint32_t cx = col0 + lx, r = row0 + ly;
     const bool valid = cx < p.ncols && r < p.nrows;
-    render_pixel<T, MODE>(p, out, s_tab, s_re[lx], s_im[ly], valid, cx, r, lane);
+    render_pixel<T, MODE>(p, out, s_tab, nullptr, s_re[lx], s_im[ly], valid, cx, r, lane);
 }
 
 /* Default kernel: ONE WAVE PER WORKGROUP renders a horizontal strip of kStripTiles 8x8 tiles
@@ -505,11 +519,19 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
 
 template <typename T, int MODE, int kStripTiles>
 __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, const fr_kout out) {
-    __shared__ double s_tab[FR_LOG2_N * 3];
+    /* one LDS array, two uses: the log2 table (smooth colouring) or the palette (smooth == false) */
+    __shared__ double s_tab[(FR_LOG2_N * 3 * 8 > FR_MAX_PALETTE_ENTRIES * 4 ? FR_LOG2_N * 3 * 8 : FR_MAX_PALETTE_ENTRIES * 4) / 8];
     const uint32_t tid = threadIdx.x;
+    const uint32_t *s_pal = nullptr;
     if (MODE == FR_OUT_RGB) {
-        const double *gt = &g_log2_tab[0][0];
-        for (uint32_t k = tid; k < FR_LOG2_N * 3; k += 64) s_tab[k] = gt[k];
+        if (p.palette != nullptr) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_tab);
+            for (uint32_t k = tid; k < p.palette_entries; k += 64) dst[k] = p.palette[k];
+            s_pal = dst;
+        } else if (p.smooth) {
+            const double *gt = &g_log2_tab[0][0];
+            for (uint32_t k = tid; k < FR_LOG2_N * 3; k += 64) s_tab[k] = gt[k];
+        }
         __syncthreads();
     }
     const uint32_t lane = tid;
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
         const double sre = __shfl(re_lane, lx, 64);
         const uint32_t cx = col0 + lx;
         const bool valid = cx < p.ncols && r < p.nrows;
-        render_pixel<T, MODE>(p, out, s_tab, sre, sim, valid, cx, r, lane);
+        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane);
     }
 }
 
@@ -639,6 +661,17 @@ __global__ __launch_bounds__(256) void recursive_batch_kernel(uint32_t iteration
     out_iters[k] = it;
 }
 
+/* palette[i] for i = 0 .. iterations: the outside colour of escape index i when smooth == false
+ * (calc/src/lib.rs:228-229 with `iters` an integer) — exactly the per-pixel computation, done once */
+__global__ __launch_bounds__(256) void palette_kernel(const fr_kparams p, uint32_t *palette) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > p.iterations) return;
+    const ColourConsts cc = make_colour_consts(p);
+    uint8_t rgb[3];
+    colour_outside_flat(cc, i, rgb);
+    palette[i] = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16);
+}
+
 __global__ __launch_bounds__(256) void math_probe_kernel(int which, const double *in, double *out, size_t n) {
     __shared__ double s_tab[FR_LOG2_N * 3];
     const double *gt = &g_log2_tab[0][0];
@@ -679,6 +712,12 @@ hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, c
     else
         hipLaunchKernelGGL(recursive_batch_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, stream, iterations,
                            start, c, n, limit, out_pos, out_iters);
+    return hipGetLastError();
+}
+
+hipError_t fr_launch_palette(const fr_kparams &p, uint32_t *palette, hipStream_t stream) {
+    const uint32_t entries = p.iterations + 1;
+    hipLaunchKernelGGL(palette_kernel, dim3((entries + 255) / 256), dim3(256), 0, stream, p, palette);
     return hipGetLastError();
 }
 

@@ -182,6 +182,11 @@ int fr_last_kernel_ms(float *ms);
  * kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave pixel footprint. */
 int fr_set_tile(int tile);
 
+/* smooth == false renders look the outside colour up in an LDS-staged palette (one entry per
+ * escape index, built once per call on the device) when iterations < 1280; 0 disables that and
+ * computes the colour per pixel.  Same bytes either way (tests compare them). */
+int fr_set_palette(int enabled);
+
 /* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled
  * loop with an escape check every iteration; 4 / 2 = the scaled loop that checks every 4th / 2nd
  * iteration, used only where it is provably bit-identical (otherwise the call still falls back to

@@ -247,6 +247,24 @@ def test_limits_with_nonzero_low_mantissa_bits(fr, limit, mode):
         _native.load().fr_set_loop_mode(-1)
 
 
+@pytest.mark.parametrize("palette", [1, 0])
+@pytest.mark.parametrize("iterations", [1, 3, 50, 1024, 1279, 1280, 3000])
+def test_unsmooth_palette_lookup(fr, palette, iterations):
+    """smooth == false (-u): the LDS-staged palette path and the per-pixel path give the oracle's bytes."""
+    from fractal_renderer_amd import _native
+
+    ocfg = O.cli_config(200, 120, iterations=iterations, smooth=0, exposure=7.0)
+    cfg = to_fr(fr, ocfg)
+    try:
+        _native.check(_native.load().fr_set_palette(palette))
+        for op, fp in ((O.F64, fr.Precision.F64), (O.F32, fr.Precision.F32)):
+            assert np.array_equal(fr.get_image(cfg, fp), oracle_image(ocfg, op, soft=False)), (palette, iterations, op)
+        jcfg = O.cli_config(120, 90, O.JULIA, julia_set=(-0.8, 0.156), iterations=iterations, smooth=0, inside=0)
+        assert np.array_equal(fr.get_image(to_fr(fr, jcfg)), oracle_image(jcfg, soft=False))
+    finally:
+        _native.load().fr_set_palette(1)
+
+
 TINY_CASES = {
     # orbits whose products pass through the subnormal range: the scaled loop must not be used
     "julia_c_zero": dict(algo=O.JULIA, julia_set=(0.0, 0.0), iterations=40),
