@@ -17,6 +17,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/fractal_hip.h"
 #include "fr_kernels.h"
@@ -46,7 +47,9 @@ struct State {
     std::mutex mu; /* serialises the host-buffer entry points (they share stream + scratch) */
     bool inited = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      /* kernels of the host-buffer entry points */
+    hipStream_t copy_stream = nullptr; /* their D2H copies, overlapped with the next band's kernel */
+    std::vector<hipEvent_t> band_done;
     Scratch rgb, z, iters, misc;
 };
 State g;
@@ -74,6 +77,16 @@ int fail_hip(hipError_t e, const char *what) {
     } while (0)
 
 /* caller holds g.mu */
+void release_streams_locked() {
+    for (hipEvent_t e : g.band_done) (void)hipEventDestroy(e);
+    g.band_done.clear();
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
+    g.stream = nullptr;
+    g.copy_stream = nullptr;
+}
+
+/* caller holds g.mu */
 int init_locked(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -91,12 +104,12 @@ int init_locked(int device) {
             if (s->ptr) (void)hipFree(s->ptr);
             *s = Scratch();
         }
-        if (g.stream) (void)hipStreamDestroy(g.stream);
-        g.stream = nullptr;
+        release_streams_locked();
         g.inited = false;
     }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
     g.device = device;
     g.inited = true;
     return FR_OK;
@@ -315,8 +328,7 @@ int fr_shutdown(void) {
         if (s->ptr) (void)hipFree(s->ptr);
         *s = Scratch();
     }
-    if (g.stream) (void)hipStreamDestroy(g.stream);
-    g.stream = nullptr;
+    release_streams_locked();
     g.inited = false;
     return FR_OK;
 }
@@ -441,7 +453,8 @@ int fr_render_rows_rgb8(const fr_config *cfg, int precision, uint32_t y0, uint32
     int rc = check_rows(cfg, y0, y1);
     if (rc == FR_OK) rc = check_precision(precision);
     if (rc != FR_OK) return rc;
-    const size_t need = (size_t)3 * cfg->width * (size_t)(y1 - y0);
+    const size_t row_bytes = (size_t)3 * cfg->width;
+    const size_t need = row_bytes * (size_t)(y1 - y0);
     if (need == 0) return FR_OK;
     if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
     if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*(y1-y0)");
@@ -450,10 +463,55 @@ int fr_render_rows_rgb8(const fr_config *cfg, int precision, uint32_t y0, uint32
     if (rc != FR_OK) return rc;
     rc = reserve_locked(g.rgb, need);
     if (rc != FR_OK) return rc;
-    rc = fr_render_rows_rgb8_device(cfg, precision, y0, y1, g.rgb.ptr, need, g.stream);
+    uint8_t *scratch = static_cast<uint8_t *>(g.rgb.ptr);
+    /* Large images: pin the caller's buffer for the duration of the call and render in bands of
+     * ~64 MiB, so band k's DMA to the host (PCIe, ~57 GB/s into pinned memory) runs on the copy
+     * stream while band k+1 renders — the call costs about max(kernel, copy), not their sum.
+     * (Async copies into PAGEABLE memory are staged by the runtime and measured slower than one
+     * plain copy, so without the pin — or for small images — it is one kernel + one copy.) */
+    const bool pinned = need >= ((size_t)16 << 20) && hipHostRegister(out, need, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) {
+        (void)hipGetLastError();
+        rc = fr_render_rows_rgb8_device(cfg, precision, y0, y1, scratch, need, g.stream);
+        if (rc != FR_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(out, scratch, need, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return FR_OK;
+    }
+    const size_t band_target = (size_t)64 << 20;
+    uint64_t bands = (need + band_target - 1) / band_target;
+    if (bands > 64) bands = 64;
+    uint64_t band_rows = ((uint64_t)(y1 - y0) + bands - 1) / bands;
+    band_rows = (band_rows + 7) / 8 * 8; /* whole 8-row tiles */
+    hipError_t err = hipSuccess;
+    const char *what = "";
+    size_t b = 0;
+    for (uint64_t ya = y0; ya < y1 && rc == FR_OK && err == hipSuccess; ya += band_rows, b++) {
+        const uint32_t yb = (uint32_t)(ya + band_rows < y1 ? ya + band_rows : y1);
+        const size_t off = row_bytes * (size_t)(ya - y0), bytes = row_bytes * (size_t)(yb - ya);
+        rc = fr_render_rows_rgb8_device(cfg, precision, (uint32_t)ya, yb, scratch + off, bytes, g.stream);
+        if (rc != FR_OK) break;
+        if (b >= g.band_done.size()) {
+            hipEvent_t e;
+            if ((err = hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) {
+                what = "hipEventCreateWithFlags";
+                break;
+            }
+            g.band_done.push_back(e);
+        }
+        if ((err = hipEventRecord(g.band_done[b], g.stream)) != hipSuccess) what = "hipEventRecord";
+        else if ((err = hipStreamWaitEvent(g.copy_stream, g.band_done[b], 0)) != hipSuccess) what = "hipStreamWaitEvent";
+        else if ((err = hipMemcpyAsync(out + off, scratch + off, bytes, hipMemcpyDeviceToHost, g.copy_stream)) != hipSuccess)
+            what = "hipMemcpyAsync";
+    }
+    /* always drain both streams and unpin before returning, error or not */
+    hipError_t e1 = hipStreamSynchronize(g.stream);
+    hipError_t e2 = hipStreamSynchronize(g.copy_stream);
+    (void)hipHostUnregister(out);
     if (rc != FR_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, need, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (err != hipSuccess) return fail_hip(err, what);
+    if (e1 != hipSuccess) return fail_hip(e1, "hipStreamSynchronize(stream)");
+    if (e2 != hipSuccess) return fail_hip(e2, "hipStreamSynchronize(copy_stream)");
     return FR_OK;
 }
 
@@ -579,17 +637,20 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
     std::lock_guard<std::mutex> lk(g.mu);
     rc = ensure_locked();
     if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.misc, 256);
+    const size_t slot_bytes = sizeof(unsigned long long) * FR_COUNT_SLOTS;
+    rc = reserve_locked(g.misc, slot_bytes);
     if (rc != FR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(g.misc.ptr, 0, sizeof(unsigned long long), g.stream));
+    HIP_TRY(hipMemsetAsync(g.misc.ptr, 0, slot_bytes, g.stream));
     plan_loop(cfg, precision, p);
     fr_kout o{};
     o.count = static_cast<unsigned long long *>(g.misc.ptr);
     HIP_TRY(fr_launch_escape(p, precision, FR_OUT_COUNT, o, g_tile.load(), g.stream));
-    unsigned long long host = 0;
-    HIP_TRY(hipMemcpyAsync(&host, g.misc.ptr, sizeof host, hipMemcpyDeviceToHost, g.stream));
+    std::vector<unsigned long long> host(FR_COUNT_SLOTS);
+    HIP_TRY(hipMemcpyAsync(host.data(), g.misc.ptr, slot_bytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
-    *total = host;
+    unsigned long long sum = 0;
+    for (unsigned long long v : host) sum += v;
+    *total = sum;
     return FR_OK;
 }
 

@@ -43,6 +43,9 @@ enum fr_out_mode {
     FR_OUT_COUNT = 2   /* sum of executed iterations into one uint64          */
 };
 
+/* MODE COUNT accumulates into this many uint64 partial sums (fr_kout::count points at them) */
+constexpr uint32_t FR_COUNT_SLOTS = 512;
+
 struct fr_kout {
     uint8_t *rgb;
     double *z;

@@ -457,7 +457,8 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
         unsigned long long n = 0;
         if (valid && escape_algo) n = iters < p.iterations ? (unsigned long long)iters + 1ull : p.iterations;
         for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
-        if (lane == 0 && n) atomicAdd(out.count, n);
+        /* FR_COUNT_SLOTS partial sums (the host adds them): one hot address would serialise */
+        if (lane == 0 && n) atomicAdd(out.count + ((blockIdx.x + 131u * blockIdx.y) % FR_COUNT_SLOTS), n);
     }
 }
 
