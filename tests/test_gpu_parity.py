@@ -265,6 +265,60 @@ def test_unsmooth_palette_lookup(fr, palette, iterations):
         _native.load().fr_set_palette(1)
 
 
+def _random_config(rng):
+    algo = O.JULIA if rng.random() < 0.4 else O.MANDELBROT
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 160))
+    centres = [(-0.6, 0.0), (-0.7436447860, 0.1318252536), (0.0, 0.0), (-1.25, 0.0), (0.3, 0.5), (-2.0, 0.0), (5.0, -3.0)]
+    cx, cy = centres[int(rng.integers(len(centres)))]
+    scale = float(10 ** rng.uniform(-1.5, 7))
+    kw = dict(
+        iterations=int(rng.choice([0, 1, 2, 3, 5, 17, 64, 100, 255, 300])),
+        pos=(cx + float(rng.normal(0, 0.3 / scale)), cy + float(rng.normal(0, 0.3 / scale))),
+        scale=(scale, scale * float(rng.choice([1.0, 1.0, 0.7, 1.9]))),
+        limit=float(rng.choice([65536.0, 65536.0, 2.0, 4.0, 100.0, 1000.5, 0.5, 1e10, 3.3e7])),
+        stable_limit=float(rng.choice([2.0, 2.0, 0.5, 1.5, 100.0, 0.0])),
+        exposure=float(rng.choice([5.0, 2.0, 0.3, 50.0, -1.0])),
+        inside=int(rng.random() < 0.7), smooth=int(rng.random() < 0.7),
+        primary_color=tuple(int(v) for v in rng.integers(0, 256, 3)),
+        secondary_color=tuple(int(v) for v in rng.integers(0, 256, 3)),
+    )
+    if algo == O.JULIA:
+        kw["julia_set"] = (float(rng.uniform(-1.2, 0.6)), float(rng.uniform(-0.8, 0.8)))
+        kw["pos"] = (float(rng.normal(0, 0.5)), float(rng.normal(0, 0.5)))
+        kw["scale"] = (float(10 ** rng.uniform(-0.7, 2)),) * 2
+    return O.cli_config(w, h, algo, **kw)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configs_differential(fr, seed):
+    """Seeded random Configs (sizes, views, limits, flags, colours, both algorithms, both precisions,
+    every kernel variant and loop form): colours, escape indices and final positions vs the oracle."""
+    from fractal_renderer_amd import _native
+
+    rng = np.random.default_rng(1000 + seed)
+    lib = _native.load()
+    try:
+        for _ in range(4):
+            ocfg = _random_config(rng)
+            cfg = to_fr(fr, ocfg)
+            f32 = rng.random() < 0.35
+            op, fp = (O.F32, fr.Precision.F32) if f32 else (O.F64, fr.Precision.F64)
+            _native.check(lib.fr_set_tile(int(rng.choice([0, 0, 1, 2, 4, 8, 808, 1604, 3202, 6401]))))
+            _native.check(lib.fr_set_loop_mode(int(rng.choice([-1, -1, 0, 2, 4]))))
+            _native.check(lib.fr_set_palette(int(rng.random() < 0.7)))
+            desc = (seed, bytes(ocfg).hex(), f32)
+            z, it = fr.escape_rows(cfg, precision=fp)
+            wz, wit = O.escape_rows(ocfg, op)
+            assert np.array_equal(it, wit), desc
+            assert same_f64(z, wz), desc
+            assert np.array_equal(fr.get_image(cfg, fp), oracle_image(ocfg, op)), desc
+            assert fr.count_iterations(cfg, precision=fp)[0] == O.count_iterations(ocfg, op), desc
+    finally:
+        lib.fr_set_tile(0)
+        lib.fr_set_loop_mode(-1)
+        lib.fr_set_palette(1)
+
+
 TINY_CASES = {
     # orbits whose products pass through the subnormal range: the scaled loop must not be used
     "julia_c_zero": dict(algo=O.JULIA, julia_set=(0.0, 0.0), iterations=40),
@@ -426,6 +480,28 @@ def test_full_size_c2_sampled_against_oracle(fr):
     # any row band rendered on its own equals the same rows of the full render
     band = fr.get_image_rows(cfg, 8000, 8192)
     assert np.array_equal(band, img[8000:8192])
+
+
+def test_full_size_c5_65536_squared_on_one_device(fr):
+    """BASELINE C5's image (65536^2 = 2^32 pixels, 12.9 GB) rendered whole on ONE device: every
+    index is past 32 bits.  Every 64th pixel in x and y against the oracle, the exact iteration sum on
+    that sample, and the mirror symmetry of the default view."""
+    ocfg = O.cli_config(65536, 65536, iterations=1024)
+    cfg = to_fr(fr, ocfg)
+    img = fr.get_image(cfg)
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        total, npx, want = O.sample_image(ocfg, 64, 64)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+    assert np.array_equal(img[::64, ::64], want)
+    assert fr.count_iterations(cfg, sx=64, sy=64) == (total, npx)
+    assert np.array_equal(img[1:4096], img[65535:61440:-1])          # top rows mirror the bottom rows
+    assert np.array_equal(img[32768 - 2048:32768], img[32768 + 2048:32768:-1])
+    # the last rows rendered on their own (byte offsets > 2^33 in the full image) equal the full render
+    band = fr.get_image_rows(cfg, 65536 - 24, 65536)
+    assert np.array_equal(band, img[65536 - 24:])
+    del img
 
 
 def test_bench_smoke_small():
