@@ -511,10 +511,10 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
  * longer the strip: a CU does not backfill the slots of a workgroup's finished waves while one of
  * its waves is still deep inside the set — 4 waves x 8 tiles ran C2 in 22.6 ms against 14.6 ms for
  * 4 waves x 1 tile.  A one-wave workgroup has nothing to wait for.)
- *   - the coordinate map (calc/src/lib.rs:181-197) of a tile is evaluated by 16 lanes of the wave
- *     itself (lanes 0-7: the 8 column values, lanes 8-15: the 8 row values — re depends only on x,
- *     im only on y) and distributed to the 64 lanes with two cross-lane reads (ds_bpermute), no LDS
- *     storage and no barrier;
+ *   - the coordinate map (calc/src/lib.rs:181-197) of the whole strip is evaluated once by the wave
+ *     itself (re depends only on x, im only on y: column lanes + 8 row lanes, one pass of the two
+ *     IEEE divisions) and handed to the 64 pixel lanes with cross-lane reads (ds_bpermute) — no
+ *     LDS storage, no barrier;
  *   - there are still >> 256 workgroups (C2: 524 288) for the dispatcher to balance.
  * The grid is 2-D/3-D, so no integer division is needed to find a tile. */
 
@@ -542,26 +542,27 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
     const uint32_t r = row0 + ly;
     const double width = (double)p.width, height = (double)p.height;
 
-    /* lanes 8-15 hold this strip's 8 row coordinates for the whole loop */
-    double im_lane = 0.0;
-    if (lane >= 8 && lane < 16) {
-        const uint32_t rr = row0 + (lane - 8);
-        const uint32_t y = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
-        im_lane = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
-    }
-    const double sim = __shfl(im_lane, 8 + ly, 64);
-    const double x_offset = (width / height) / 2.0;
-
+    /* The coordinate map of the whole strip in ONE pass: lanes 0 .. 8*kStripTiles-1 evaluate the
+     * strip's column coordinates, lanes 56-63 its 8 row coordinates — the same expression
+     * ((coord / height) - offset) / scale + pos with per-lane operands (calc/src/lib.rs:182-197). */
+    static_assert(kStripTiles <= 7, "lanes 56-63 are the row lanes");
+    const bool row_lane = lane >= 56;
     const uint32_t tile0 = blockIdx.x * kStripTiles;
+    uint32_t coord_u;
+    if (row_lane) {
+        const uint32_t rr = row0 + (lane - 56);
+        coord_u = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
+    } else {
+        coord_u = p.x_first + (tile0 * 8u + lane) * p.x_stride;
+    }
+    const double coord_lane = coord_to_space((double)coord_u, height, row_lane ? 0.5 : (width / height) / 2.0,
+                                             row_lane ? p.pos_im : p.pos_re, row_lane ? p.scale_im : p.scale_re);
+    const double sim = __shfl(coord_lane, 56 + ly, 64);
+
     for (int k = 0; k < kStripTiles; k++) {
         const uint32_t col0 = (tile0 + k) * 8u;
         if (col0 >= p.ncols) break; /* wave-uniform */
-        double re_lane = 0.0;
-        if (lane < 8) {
-            const uint32_t x = p.x_first + (col0 + lane) * p.x_stride;
-            re_lane = coord_to_space((double)x, height, x_offset, p.pos_re, p.scale_re);
-        }
-        const double sre = __shfl(re_lane, lx, 64);
+        const double sre = __shfl(coord_lane, k * 8 + lx, 64);
         const uint32_t cx = col0 + lx;
         const bool valid = cx < p.ncols && r < p.nrows;
         render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane);
@@ -629,12 +630,13 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         /* strip length by image size: long strips amortise the per-workgroup setup, short ones
          * keep every SIMD supplied with several waves when the image is small (GUI frames) */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
+        if (tiles >= 262144) return launch_strips<T, 7>(p, mode, out, stream);
         if (tiles >= 65536) return launch_strips<T, 4>(p, mode, out, stream);
         if (tiles >= 16384) return launch_strips<T, 2>(p, mode, out, stream);
         return launch_strips<T, 1>(p, mode, out, stream);
     }
     case 8:
-        return launch_strips<T, 8>(p, mode, out, stream);
+        return launch_strips<T, 7>(p, mode, out, stream);
     case 1:
         return launch_strips<T, 1>(p, mode, out, stream);
     case 2:

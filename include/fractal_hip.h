@@ -178,7 +178,7 @@ int fr_last_kernel_ms(float *ms);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
  * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
- * 1, 2, 4, 8 = that kernel with a fixed strip length; 6401, 3202, 1604, 808 = the 4-wave-workgroup
+ * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest); 6401, 3202, 1604, 808 = the 4-wave-workgroup
  * kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave pixel footprint. */
 int fr_set_tile(int tile);
 
