@@ -250,8 +250,12 @@ def main():
                 "algorithmic_flops_per_launch": FLOPS_PER_ITERATION * launch_px_it,
                 "frac_of_attainable_no_fma": (VALU_OPS_PER_ITERATION * launch_px_it / (kavg * 1e-3)) / (peak / 2 * 1e12)
                 if kavg > 0 else 0.0,
-                "note": "fp64 VECTOR peak (no MFMA, not HBM: 3 B/pixel written once). FMA is forbidden by "
-                        "bit-exactness, so the attainable ceiling is peak/2 lane-ops/s at 8 VALU ops/iteration.",
+                "hbm_check": {"algorithmic_bytes_per_launch": 3 * pixels // world,
+                              "achieved_GBps": 3 * pixels / world / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0,
+                              "peak_GBps": 8000.0},
+                "note": "bound = fp64 VECTOR issue rate (no MFMA; not HBM: 3 B/pixel written once, see hbm_check). "
+                        "frac_of_attainable_no_fma prices SURVEY.md's 8-VALU-op iteration without FMA (peak/2 "
+                        "lane-ops/s); the scaled loop issues 6.5 per iteration, so that figure is not a ceiling.",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
