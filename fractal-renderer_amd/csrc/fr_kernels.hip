@@ -145,6 +145,11 @@ __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, ui
     "s_cbranch_scc1 .Lrec" TAG "_%=\n"             \
     ".Lcont" TAG "_%=:\n"
 
+/* Taken only on iterations where EXEC changed: write the escape index of the lanes that just left,
+ * then decide whether the wave keeps going.  It stops when no lane is left, or — for the refilling
+ * kernel — when at most `thr` lanes are still running and at least `minrun` iterations have been
+ * done, so that the idle lanes can be given new pixels (thr = 0 and minrun = 0 reproduce "run until
+ * every lane has escaped").  %[si] leaves the block holding the number of iterations completed. */
 #define FR_ORBIT_RECORD(TAG, OFFSET)               \
     ".Lrec" TAG "_%=:\n"                           \
     "s_add_u32 %[stmp], %[si], " OFFSET "\n"       \
@@ -152,14 +157,21 @@ __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, ui
     "s_mov_b64 exec, %[sdiff]\n"                   \
     "v_mov_b32 %[it], %[stmp]\n"                   \
     "s_mov_b64 exec, %[sprev]\n"                   \
-    "s_cbranch_execnz .Lcont" TAG "_%=\n"          \
+    "s_cbranch_execz .Lquit" TAG "_%=\n"           \
+    "s_bcnt1_i32_b64 %[scnt], exec\n"              \
+    "s_cmp_gt_u32 %[scnt], %[thr]\n"               \
+    "s_cbranch_scc1 .Lcont" TAG "_%=\n"            \
+    "s_cmp_lt_u32 %[stmp], %[minrun]\n"            \
+    "s_cbranch_scc1 .Lcont" TAG "_%=\n"            \
+    ".Lquit" TAG "_%=:\n"                          \
+    "s_add_u32 %[si], %[stmp], 1\n"                \
     "s_branch .Ldone_%=\n"
 
 #define FR_ORBIT_ASM(SFX)                                                          \
     "s_mov_b64 %[sorig], exec\n"                                                   \
     "v_mov_b32 %[it], %[n]\n"                                                      \
-    "s_cbranch_execz .Ldone_%=\n"                                                  \
     "s_mov_b32 %[si], 0\n"                                                         \
+    "s_cbranch_execz .Ldone_%=\n"                                                  \
     "s_and_b32 %[nrem], %[n], 3\n"                                                 \
     "s_cbranch_scc0 .Lmainentry_%=\n"                                              \
     ".Lrem_%=:\n" FR_ORBIT_STEP(SFX, "R")                                          \
@@ -179,37 +191,54 @@ __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, ui
     ".Ldone_%=:\n"                                                                 \
     "s_mov_b64 exec, %[sorig]\n"
 
+/* The wave-control knobs of one run of the loop ("episode"): stop early when at most `thr` lanes are
+ * still running and at least `minrun` iterations have been done.  {0, 0} = run until every lane has
+ * escaped or the cap is reached. */
+struct EpisodeCtl {
+    uint32_t thr, minrun;
+};
+
+/* Runs up to `iterations` steps of recursive() for the active lanes.  Returns, per lane, the index
+ * (0-based, within this run) of the iteration at which it escaped, or a value >= `completed` if it
+ * is still running; `completed` (wave-uniform) = iterations every still-running lane has done. */
 template <typename T>
-__device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
-                                          T &r2, T &i2) {
-    r2 = re * re;
-    i2 = im * im;
+__device__ __forceinline__ uint32_t orbit_run(uint32_t iterations, T &re, T &im, T cre, T cim, T squared, T &r2,
+                                              T &i2, EpisodeCtl ctl, uint32_t &completed) {
     uint32_t it;
     T t, x;
     unsigned long long sorig, sprev, sdiff;
-    uint32_t si, stmp, nrem;
+    uint32_t si, stmp, nrem, scnt;
     const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
+    const uint32_t thr = __builtin_amdgcn_readfirstlane(ctl.thr), minrun = __builtin_amdgcn_readfirstlane(ctl.minrun);
+#define FR_ORBIT_OPERANDS                                                                                          \
+    : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t), [x] "=&v"(x),      \
+      [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),        \
+      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt)                                                                       \
+    : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n), [thr] "s"(thr), [minrun] "s"(minrun)           \
+    : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
         /* limit^2 is wave-uniform: pin it in an SGPR pair (v_cmpx's src0) */
         const uint64_t sq_bits = fr_bits_of(squared);
         const uint64_t lim2 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sq_bits) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sq_bits >> 32)) << 32);
-        asm volatile(FR_ORBIT_ASM("f64")
-                     : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t),
-                       [x] "=&v"(x), [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff),
-                       [si] "=&s"(si), [stmp] "=&s"(stmp), [nrem] "=&s"(nrem)
-                     : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n)
-                     : "vcc", "scc");
+        asm volatile(FR_ORBIT_ASM("f64") FR_ORBIT_OPERANDS);
     } else {
         const uint32_t lim2 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, squared));
-        asm volatile(FR_ORBIT_ASM("f32")
-                     : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t),
-                       [x] "=&v"(x), [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff),
-                       [si] "=&s"(si), [stmp] "=&s"(stmp), [nrem] "=&s"(nrem)
-                     : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n)
-                     : "vcc", "scc");
+        asm volatile(FR_ORBIT_ASM("f32") FR_ORBIT_OPERANDS);
     }
+    completed = si;
     return it;
+}
+
+/* recursive() from the start: (re, im) in/out, r2 = re*re and i2 = im*im of the returned position,
+ * result = the escape index (== iterations on exhaustion). */
+template <typename T>
+__device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
+                                          T &r2, T &i2) {
+    r2 = re * re;
+    i2 = im * im;
+    uint32_t completed;
+    return orbit_run<T>(iterations, re, im, cre, cim, squared, r2, i2, EpisodeCtl{0, 0}, completed);
 }
 
 /* ---- orbit loop, scaled form ------------------------------------------------------------------
@@ -257,9 +286,9 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
 #define FR_SC_ASM(SFX, MSTR, FAST_ITS, SLOW_STEPS, SLOW_RECORDS)                   \
     "s_mov_b64 %[sorig], exec\n"                                                   \
     "v_mov_b32 %[it], %[n]\n"                                                      \
-    "s_cbranch_execz .Ldone_%=\n"                                                  \
-    "v_add_" SFX " %[t], %[A], %[B]\n"                                             \
     "s_mov_b32 %[si], 0\n"                                                         \
+    "s_cbranch_execz .Ldone_%=\n"                                                  \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                                                         \
     "s_and_b32 %[nrem], %[n], " MSTR "-1\n"                                        \
     "s_cbranch_scc0 .Lmodesel_%=\n"                                                \
     ".Lrem_%=:\n" FR_SC_CHECKED_STEP(SFX, "R")                                     \
@@ -290,6 +319,11 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "v_mov_b32 %[it], %[stmp]\n"                                                   \
     "s_mov_b64 exec, %[sprev]\n"                                                   \
     "s_cbranch_execz .Ldone_%=\n"                                                  \
+    "s_bcnt1_i32_b64 %[scnt], exec\n"                                              \
+    "s_cmp_gt_u32 %[scnt], %[thr]\n"                                               \
+    "s_cbranch_scc1 .Lfxnorec_%=\n"                                                \
+    "s_cmp_lt_u32 %[si], %[minrun]\n"                                              \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
     ".Lfxnorec_%=:\n"                                                              \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc0 .Ldone_%=\n"                                                   \
@@ -335,31 +369,32 @@ __device__ __forceinline__ bool lane_is_scalable(T re0, T im0, T cre, T cim) {
     return c_ok(cre) && c_ok(cim) && s_ok(re0) && s_ok(im0);
 }
 
-/* M = 4 or 2.  Same contract as orbit(): (re, im) in/out, r2/i2 out, returns the escape index.
- * `squared` = limit^2 (of T), `skip_t` = the host's threshold T on fl(re^2+im^2). */
+/* One run of the scaled loop on state (X, Y, A, B) = (2re, 2im, X*X, Y*Y); M = 4 or 2.  Same
+ * return convention as orbit_run().  `squared` = limit^2 (of T), `skip_t` = the host's threshold T
+ * on fl(re^2+im^2). */
 template <typename T, int M>
-__device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
-                                                 T skip_t, T &r2, T &i2) {
-    T X = re + re, Y = im + im, A = X * X, B = Y * Y;
-    const T c2re = cre + cre, c2im = cim + cim;
+__device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, T &Y, T &A, T &B, T c2re, T c2im,
+                                                     T squared, T skip_t, EpisodeCtl ctl, uint32_t &completed) {
     uint32_t it;
     T t, q;
     unsigned long long sorig, sprev, sdiff;
-    uint32_t si, stmp, nrem;
+    uint32_t si, stmp, nrem, scnt;
     const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
+    const uint32_t thr = __builtin_amdgcn_readfirstlane(ctl.thr), minrun = __builtin_amdgcn_readfirstlane(ctl.minrun);
     const T lim4_v = (T)4 * squared, t4_v = (T)4 * skip_t;
+#define FR_SC_OPERANDS                                                                                          \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [it] "=&v"(it), [t] "=&v"(t), [q] "=&v"(q),           \
+      [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),     \
+      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt)                                                                    \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n), [thr] "s"(thr),     \
+      [minrun] "s"(minrun)                                                                                      \
+    : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
         const uint64_t lb = fr_bits_of(lim4_v), tb = fr_bits_of(t4_v);
         const uint64_t lim4 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lb) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lb >> 32)) << 32);
         const uint64_t t4lim = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)tb) |
                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32);
-#define FR_SC_OPERANDS                                                                                          \
-    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [it] "=&v"(it), [t] "=&v"(t), [q] "=&v"(q),           \
-      [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),     \
-      [nrem] "=&s"(nrem)                                                                                        \
-    : [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n)                      \
-    : "vcc", "scc"
         if constexpr (M == 4)
             asm volatile(FR_SC_ASM_M4("f64") FR_SC_OPERANDS);
         else
@@ -372,6 +407,18 @@ __device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &
         else
             asm volatile(FR_SC_ASM_M2("f32") FR_SC_OPERANDS);
     }
+    completed = si;
+    return it;
+}
+
+/* recursive() from the start through the scaled loop.  Same contract as orbit(). */
+template <typename T, int M>
+__device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
+                                                 T skip_t, T &r2, T &i2) {
+    T X = re + re, Y = im + im, A = X * X, B = Y * Y;
+    uint32_t completed;
+    const uint32_t it = orbit_scaled_run<T, M>(iterations, X, Y, A, B, cre + cre, cim + cim, squared, skip_t,
+                                               EpisodeCtl{0, 0}, completed);
     re = X * (T)0.5; /* exact */
     im = Y * (T)0.5;
     r2 = re * re; /* recomputed from the final position: the reference's own re*re, im*im */
