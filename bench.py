@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--view", choices=["default", "zoom1e6", "julia"], default="default")
     ap.add_argument("--block-rows", type=int, default=256)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--refill", default="", help="tuning: minrun,quit16 of the refilling kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores available)")
     return ap.parse_args()
@@ -130,6 +131,9 @@ def main():
     fr.init(local_rank)
     lib = _native.load()
     _native.check(lib.fr_set_tile(args.tile))
+    if args.refill:
+        mr, q16 = (int(v) for v in args.refill.split(","))
+        _native.check(lib.fr_set_refill_policy(mr, q16))
     device = torch.device("cuda", local_rank)
     prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
 

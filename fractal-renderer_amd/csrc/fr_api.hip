@@ -55,6 +55,7 @@ struct State {
 State g;
 std::atomic<int> g_tile{0};
 std::atomic<int> g_palette_enabled{1};
+std::atomic<int> g_refill_minrun{32}, g_refill_quit16{8};
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 
 int fail(int code, const char *what) {
@@ -167,6 +168,8 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.block_rows = 1;
     p.y_first = 0;
     p.y_stride = 1;
+    p.refill_minrun = (uint32_t)g_refill_minrun.load();
+    p.refill_quit16 = (uint32_t)g_refill_quit16.load();
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
@@ -259,7 +262,7 @@ int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_ou
     uint32_t *palette = nullptr;
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     if (!cfg->smooth && escape_algo && g_palette_enabled.load() && cfg->iterations < FR_MAX_PALETTE_ENTRIES &&
-        g_tile.load() <= 8) {
+        g_tile.load() <= 9) {
         HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&palette), sizeof(uint32_t) * (cfg->iterations + 1), stream));
         p.palette = palette;
         p.palette_entries = cfg->iterations + 1;
@@ -675,6 +678,7 @@ int fr_set_tile(int tile) {
     case 2:
     case 4:
     case 8:
+    case 9:
     case 6401:
     case 3202:
     case 1604:
@@ -682,8 +686,15 @@ int fr_set_tile(int tile) {
         g_tile.store(tile);
         return FR_OK;
     default:
-        return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 6401, 3202, 1604 or 808");
+        return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 6401, 3202, 1604 or 808");
     }
+}
+
+int fr_set_refill_policy(int minrun, int quit16) {
+    if (minrun < 0 || quit16 < 1 || quit16 > 16) return fail(FR_ERR_INVALID_ARGUMENT, "minrun >= 0, 1 <= quit16 <= 16");
+    g_refill_minrun.store(minrun);
+    g_refill_quit16.store(quit16);
+    return FR_OK;
 }
 
 int fr_set_palette(int enabled) {

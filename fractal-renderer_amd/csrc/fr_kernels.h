@@ -35,6 +35,9 @@ struct fr_kparams {
      * escape index is i (0 .. iterations), built by fr_launch_palette; NULL = compute per pixel */
     const uint32_t *palette;
     uint32_t palette_entries;
+    /* refilling kernel: an episode may end early once `refill_quit16`/16 of its running lanes have
+     * finished and `refill_minrun` iterations were done (see fr_kernels.hip) */
+    uint32_t refill_minrun, refill_quit16;
 };
 
 enum fr_out_mode {

@@ -178,9 +178,15 @@ int fr_last_kernel_ms(float *ms);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
  * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
- * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest); 6401, 3202, 1604, 808 = the 4-wave-workgroup
+ * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
+ * 9 = 7-tile strips with lane refill (the default for large Julia images); 6401, 3202, 1604, 808 = the 4-wave-workgroup
  * kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave pixel footprint. */
 int fr_set_tile(int tile);
+
+/* Policy of the lane-refilling kernel (tuning studies): an orbit episode may end early, so that
+ * idle lanes get new pixels, once quit16/16 of its running lanes have finished and at least `minrun`
+ * iterations were done.  Does not affect results. */
+int fr_set_refill_policy(int minrun, int quit16);
 
 /* smooth == false renders look the outside colour up in an LDS-staged palette (one entry per
  * escape index, built once per call on the device) when iterations < 1280; 0 disables that and

@@ -185,7 +185,7 @@ def test_golden_vectors(fr, key):
     assert total == G.MANIFEST[key]["executed_iterations"] and npx == cfg.width * cfg.height
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 4, 8, 6401, 3202, 1604, 808])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 8, 9, 6401, 3202, 1604, 808])
 def test_every_tile_shape_gives_the_same_bytes(fr, tile):
     from fractal_renderer_amd import _native
 
@@ -303,7 +303,7 @@ def test_random_configs_differential(fr, seed):
             cfg = to_fr(fr, ocfg)
             f32 = rng.random() < 0.35
             op, fp = (O.F32, fr.Precision.F32) if f32 else (O.F64, fr.Precision.F64)
-            _native.check(lib.fr_set_tile(int(rng.choice([0, 0, 1, 2, 4, 8, 808, 1604, 3202, 6401]))))
+            _native.check(lib.fr_set_tile(int(rng.choice([0, 0, 1, 2, 4, 8, 9, 9, 9, 808, 1604, 3202, 6401]))))
             _native.check(lib.fr_set_loop_mode(int(rng.choice([-1, -1, 0, 2, 4]))))
             _native.check(lib.fr_set_palette(int(rng.random() < 0.7)))
             desc = (seed, bytes(ocfg).hex(), f32)
