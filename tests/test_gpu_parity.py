@@ -399,6 +399,27 @@ def test_logical_block_cyclic_partitions_on_one_device(fr, world, block_rows):
     assert np.array_equal(img.reshape(cfg.height, cfg.width, 3), want)
 
 
+@pytest.mark.parametrize("w,h", [(3, 300001), (500003, 2), (8, 262145 + 64)])
+def test_extreme_aspect_ratios(fr, w, h):
+    """More than 32768 row tiles (3-D grid path) and very wide images; every pixel against the oracle."""
+    ocfg = O.cli_config(w, h, iterations=40, scale=(0.4 * w / max(h, 1), 0.4) if w > h else (0.4, 0.4))
+    cfg = to_fr(fr, ocfg)
+    assert np.array_equal(fr.get_image(cfg), oracle_image(ocfg))
+    assert fr.count_iterations(cfg)[0] == O.count_iterations(ocfg)
+
+
+def test_iteration_cap_extremes(fr):
+    """iterations = u32::MAX with a limit every orbit exceeds at once, and iterations not a multiple
+    of the unroll factors."""
+    for it in (4294967295, 4294967294, 7, 6, 5):
+        ocfg = O.cli_config(40, 24, iterations=it, limit=1e-3, stable_limit=0.0)
+        cfg = to_fr(fr, ocfg)
+        z, iters = fr.escape_rows(cfg)
+        wz, wit = O.escape_rows(ocfg)
+        assert np.array_equal(iters, wit) and same_f64(z, wz), it
+        assert np.array_equal(fr.get_image(cfg), oracle_image(ocfg)), it
+
+
 def test_get_recursive_pixel_outside_the_image(fr):
     # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
     ocfg = O.cli_config(64, 48, iterations=80)
