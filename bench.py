@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--block-rows", type=int, default=256)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--refill", default="", help="tuning: minrun,quit16 of the refilling kernel")
+    ap.add_argument("--cycle-shortcut", action="store_true",
+                    help="measure with the exact periodicity shortcut on (never the headline: it skips iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores available)")
     return ap.parse_args()
@@ -131,6 +133,8 @@ def main():
     fr.init(local_rank)
     lib = _native.load()
     _native.check(lib.fr_set_tile(args.tile))
+    if args.cycle_shortcut:
+        _native.check(lib.fr_set_cycle_shortcut(1))
     if args.refill:
         mr, q16 = (int(v) for v in args.refill.split(","))
         _native.check(lib.fr_set_refill_policy(mr, q16))
@@ -187,6 +191,25 @@ def main():
             _native.check(lib.fr_last_kernel_ms(C.byref(ms)))
             kernel_ms.append(ms.value)
         del share
+
+    # Extra, never the headline: the same steps with the exact periodicity shortcut on (bit-identical
+    # output, but periodic orbits are fast-forwarded instead of iterated, so it is not a roofline number)
+    shortcut = None
+    if world == 1 and not args.cycle_shortcut:
+        _native.check(lib.fr_set_cycle_shortcut(1))
+        _native.check(lib.fr_set_profiling(0))
+        ref = img.clone() if img is not None else None
+        renderer.render()
+        fence()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            img2 = renderer.render()
+        fence()
+        shortcut = {"ms_per_step": (time.perf_counter() - ts) / args.steps * 1e3,
+                    "bytes_identical_to_plain_loop": bool(torch.equal(ref, img2))}
+        _native.check(lib.fr_set_cycle_shortcut(0))
+        _native.check(lib.fr_set_profiling(1))
+        img = ref
 
     # exact Σ executed iterations of the whole image, counted on the device outside the timed region
     y0 = cfg.height * rank // world
@@ -262,6 +285,12 @@ def main():
                         "lane-ops/s); the scaled loop issues 6.5 per iteration, so that figure is not a ceiling.",
             },
         }
+        if shortcut is not None:
+            shortcut["value"] = total / (shortcut["ms_per_step"] * 1e-3)
+            shortcut["note"] = ("fr_set_cycle_shortcut(1): orbits that return bitwise to an earlier state are "
+                                "fast-forwarded to the cap; same bytes, fewer iterations executed; off by default "
+                                "and excluded from `value` and `roofline`")
+            out["exact_cycle_shortcut"] = shortcut
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
             info, colours, cpu_total, (sx, sy) = cpu_baseline(bytes(cfg), int(prec), threads)

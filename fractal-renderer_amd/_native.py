@@ -123,6 +123,7 @@ PROTOTYPES = {
     "fr_set_tile": (C.c_int, [C.c_int]),
     "fr_set_loop_mode": (C.c_int, [C.c_int]),
     "fr_set_palette": (C.c_int, [C.c_int]),
+    "fr_set_cycle_shortcut": (C.c_int, [C.c_int]),
     "fr_set_refill_policy": (C.c_int, [C.c_int, C.c_int]),
     "fr_debug_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
 }

@@ -55,6 +55,7 @@ struct State {
 State g;
 std::atomic<int> g_tile{0};
 std::atomic<int> g_palette_enabled{1};
+std::atomic<int> g_cycle_shortcut{0};
 std::atomic<int> g_refill_minrun{32}, g_refill_quit16{8};
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 
@@ -170,6 +171,8 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.y_stride = 1;
     p.refill_minrun = (uint32_t)g_refill_minrun.load();
     p.refill_quit16 = (uint32_t)g_refill_quit16.load();
+    /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
+    p.cycle_shortcut = (g_cycle_shortcut.load() && cfg->iterations < (1u << 30)) ? 1u : 0u;
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
@@ -694,6 +697,11 @@ int fr_set_refill_policy(int minrun, int quit16) {
     if (minrun < 0 || quit16 < 1 || quit16 > 16) return fail(FR_ERR_INVALID_ARGUMENT, "minrun >= 0, 1 <= quit16 <= 16");
     g_refill_minrun.store(minrun);
     g_refill_quit16.store(quit16);
+    return FR_OK;
+}
+
+int fr_set_cycle_shortcut(int enabled) {
+    g_cycle_shortcut.store(enabled ? 1 : 0);
     return FR_OK;
 }
 

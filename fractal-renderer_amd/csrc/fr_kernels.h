@@ -38,6 +38,9 @@ struct fr_kparams {
     /* refilling kernel: an episode may end early once `refill_quit16`/16 of its running lanes have
      * finished and `refill_minrun` iterations were done (see fr_kernels.hip) */
     uint32_t refill_minrun, refill_quit16;
+    /* exact periodicity shortcut (refilling kernel, scaled loops): an orbit found bitwise back at an
+     * earlier state is fast-forwarded to the cap instead of being iterated there; 0 = off */
+    uint32_t cycle_shortcut;
 };
 
 enum fr_out_mode {

@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_cbranch_scc1 .Lrec" TAG "_%=\n"             \
     ".Lcont" TAG "_%=:\n"
 
-#define FR_SC_ASM(SFX, MSTR, FAST_ITS, SLOW_STEPS, SLOW_RECORDS)                   \
+#define FR_SC_ASM(SFX, MSTR, FAST_ITS, SLOW_STEPS, SLOW_RECORDS, CYC_F, CYC_S, CYC_H)  \
     "s_mov_b64 %[sorig], exec\n"                                                   \
     "v_mov_b32 %[it], %[n]\n"                                                      \
     "s_mov_b32 %[si], 0\n"                                                         \
@@ -305,6 +305,7 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"                                       \
     "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
     "s_cbranch_vccnz .Lfastexit_%=\n"                                              \
+    CYC_F                                                                          \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc1 .Lfast_%=\n"                                                   \
     "s_branch .Ldone_%=\n"                                                         \
@@ -331,23 +332,56 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    CYC_S                                                                          \
     "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"                                       \
     "s_cbranch_vccz .Lfast_%=\n"                                                   \
     "s_branch .Lslow_%=\n"                                                         \
-    FR_ORBIT_RECORD("R", "0") SLOW_RECORDS                                         \
+    FR_ORBIT_RECORD("R", "0") SLOW_RECORDS CYC_H                                   \
     ".Ldone_%=:\n"                                                                 \
     "s_mov_b64 exec, %[sorig]\n"
 
-#define FR_SC_ASM_M4(SFX)                                                                          \
+/* Exact periodicity check (optional, see orbit_scaled_run): at a block end, a lane whose state
+ * (X, Y) is BITWISE equal to the state saved earlier on the same orbit (Xs, Ys) has entered an exact
+ * cycle of the floating-point map; it leaves the loop with bit 31 set in its index. */
+#define FR_SC_CYC_CHECK(EQ, TAG)                   \
+    EQ " %[scyc], %[X], %[Xs]\n"                   \
+    EQ " vcc, %[Y], %[Ys]\n"                       \
+    "s_and_b64 %[scyc], %[scyc], vcc\n"            \
+    "s_cbranch_scc1 .Lcyc" TAG "_%=\n"             \
+    ".Lcyccont" TAG "_%=:\n"
+
+#define FR_SC_CYC_HANDLER(TAG)                     \
+    ".Lcyc" TAG "_%=:\n"                           \
+    "s_or_b32 %[stmp], %[si], 0x80000000\n"        \
+    "s_mov_b64 %[sprev], exec\n"                   \
+    "s_mov_b64 exec, %[scyc]\n"                    \
+    "v_mov_b32 %[it], %[stmp]\n"                   \
+    "s_andn2_b64 exec, %[sprev], %[scyc]\n"        \
+    "s_cbranch_execz .Ldone_%=\n"                  \
+    "s_bcnt1_i32_b64 %[scnt], exec\n"              \
+    "s_cmp_gt_u32 %[scnt], %[thr]\n"               \
+    "s_cbranch_scc1 .Lcyccont" TAG "_%=\n"         \
+    "s_cmp_lt_u32 %[si], %[minrun]\n"              \
+    "s_cbranch_scc1 .Lcyccont" TAG "_%=\n"         \
+    "s_branch .Ldone_%=\n"
+
+#define FR_SC_ASM_M4_(SFX, CYC_F, CYC_S, CYC_H)                                                    \
     FR_SC_ASM(SFX, "4", FR_SC_IT(SFX) FR_SC_IT(SFX) FR_SC_IT(SFX) FR_SC_IT(SFX),                    \
               FR_SC_CHECKED_STEP(SFX, "A") FR_SC_CHECKED_STEP(SFX, "B") FR_SC_CHECKED_STEP(SFX, "C") \
                   FR_SC_CHECKED_STEP(SFX, "D"),                                                     \
               FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1") FR_ORBIT_RECORD("C", "2")         \
-                  FR_ORBIT_RECORD("D", "3"))
-#define FR_SC_ASM_M2(SFX)                                                                  \
+                  FR_ORBIT_RECORD("D", "3"),                                                        \
+              CYC_F, CYC_S, CYC_H)
+#define FR_SC_ASM_M2_(SFX, CYC_F, CYC_S, CYC_H)                                            \
     FR_SC_ASM(SFX, "2", FR_SC_IT(SFX) FR_SC_IT(SFX),                                        \
               FR_SC_CHECKED_STEP(SFX, "A") FR_SC_CHECKED_STEP(SFX, "B"),                    \
-              FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"))
+              FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"), CYC_F, CYC_S, CYC_H)
+#define FR_SC_ASM_M4(SFX) FR_SC_ASM_M4_(SFX, "", "", "")
+#define FR_SC_ASM_M2(SFX) FR_SC_ASM_M2_(SFX, "", "", "")
+#define FR_SC_ASM_M4_CYC(SFX, EQ) \
+    FR_SC_ASM_M4_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S"))
+#define FR_SC_ASM_M2_CYC(SFX, EQ) \
+    FR_SC_ASM_M2_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S"))
 
 template <typename T>
 struct ScalableRange;
@@ -371,13 +405,20 @@ __device__ __forceinline__ bool lane_is_scalable(T re0, T im0, T cre, T cim) {
 
 /* One run of the scaled loop on state (X, Y, A, B) = (2re, 2im, X*X, Y*Y); M = 4 or 2.  Same
  * return convention as orbit_run().  `squared` = limit^2 (of T), `skip_t` = the host's threshold T
- * on fl(re^2+im^2). */
-template <typename T, int M>
+ * on fl(re^2+im^2).
+ *
+ * CYC = true adds the exact periodicity check: (Xs, Ys) is a state this lane's orbit passed through
+ * earlier (or a NaN pattern = "none"); a lane found bitwise back at it after `k` completed iterations
+ * of this run returns 0x80000000 | k and stops.  The map z -> z^2 + c is a deterministic function of
+ * the state, so from then on the orbit repeats with a period dividing the distance between the two
+ * visits: the caller fast-forwards it exactly (refill_strip).  Costs 2 VALU per block. */
+template <typename T, int M, bool CYC>
 __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, T &Y, T &A, T &B, T c2re, T c2im,
-                                                     T squared, T skip_t, EpisodeCtl ctl, uint32_t &completed) {
+                                                     T squared, T skip_t, EpisodeCtl ctl, uint32_t &completed,
+                                                     T Xs = T(0), T Ys = T(0)) {
     uint32_t it;
     T t, q;
-    unsigned long long sorig, sprev, sdiff;
+    unsigned long long sorig, sprev, sdiff, scyc;
     uint32_t si, stmp, nrem, scnt;
     const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
     const uint32_t thr = __builtin_amdgcn_readfirstlane(ctl.thr), minrun = __builtin_amdgcn_readfirstlane(ctl.minrun);
@@ -385,9 +426,9 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
 #define FR_SC_OPERANDS                                                                                          \
     : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [it] "=&v"(it), [t] "=&v"(t), [q] "=&v"(q),           \
       [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),     \
-      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt)                                                                    \
+      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt), [scyc] "=&s"(scyc)                                                \
     : [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n), [thr] "s"(thr),     \
-      [minrun] "s"(minrun)                                                                                      \
+      [minrun] "s"(minrun), [Xs] "v"(Xs), [Ys] "v"(Ys)                                                          \
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
         const uint64_t lb = fr_bits_of(lim4_v), tb = fr_bits_of(t4_v);
@@ -395,18 +436,27 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lb >> 32)) << 32);
         const uint64_t t4lim = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)tb) |
                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32);
-        if constexpr (M == 4)
+        if constexpr (M == 4 && CYC)
+            asm volatile(FR_SC_ASM_M4_CYC("f64", "v_cmp_eq_u64") FR_SC_OPERANDS);
+        else if constexpr (M == 4)
             asm volatile(FR_SC_ASM_M4("f64") FR_SC_OPERANDS);
+        else if constexpr (CYC)
+            asm volatile(FR_SC_ASM_M2_CYC("f64", "v_cmp_eq_u64") FR_SC_OPERANDS);
         else
             asm volatile(FR_SC_ASM_M2("f64") FR_SC_OPERANDS);
     } else {
         const uint32_t lim4 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, lim4_v));
         const uint32_t t4lim = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, t4_v));
-        if constexpr (M == 4)
+        if constexpr (M == 4 && CYC)
+            asm volatile(FR_SC_ASM_M4_CYC("f32", "v_cmp_eq_u32") FR_SC_OPERANDS);
+        else if constexpr (M == 4)
             asm volatile(FR_SC_ASM_M4("f32") FR_SC_OPERANDS);
+        else if constexpr (CYC)
+            asm volatile(FR_SC_ASM_M2_CYC("f32", "v_cmp_eq_u32") FR_SC_OPERANDS);
         else
             asm volatile(FR_SC_ASM_M2("f32") FR_SC_OPERANDS);
     }
+    (void)scyc;
     completed = si;
     return it;
 }
@@ -417,7 +467,7 @@ __device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &
                                                  T skip_t, T &r2, T &i2) {
     T X = re + re, Y = im + im, A = X * X, B = Y * Y;
     uint32_t completed;
-    const uint32_t it = orbit_scaled_run<T, M>(iterations, X, Y, A, B, cre + cre, cim + cim, squared, skip_t,
+    const uint32_t it = orbit_scaled_run<T, M, false>(iterations, X, Y, A, B, cre + cre, cim + cim, squared, skip_t,
                                                EpisodeCtl{0, 0}, completed);
     re = X * (T)0.5; /* exact */
     im = Y * (T)0.5;
@@ -640,10 +690,31 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
-template <typename T, int MODE, int kStripTiles, int FORM>
+/* Periodicity check, Brent's schedule per pixel: a lane saves its orbit state when its own iteration
+ * count reaches 32, 64, 128, ... (episodes are cut to end exactly there) and compares against the last
+ * save at every block end.  The first save is late enough that pixels which escape within a few
+ * dozen iterations never pay for an extra episode boundary. */
+constexpr uint32_t kFirstCycleSave = 32;
+
+__device__ __forceinline__ uint32_t next_cycle_save(uint32_t done) {
+    if (done < kFirstCycleSave) return kFirstCycleSave;
+    if (done >= (1u << 30)) return 0xFFFFFFFFu;
+    return 1u << (32 - __builtin_clz(done)); /* the next power of two above `done` */
+}
+
+template <typename T>
+__device__ __forceinline__ T cycle_none() { /* a state no orbit passes through: NaN bits */
+    if constexpr (sizeof(T) == 8)
+        return __builtin_bit_cast(double, 0x7FF8000000000001ull);
+    else
+        return __builtin_bit_cast(float, 0x7FC00001u);
+}
+
+template <typename T, int MODE, int kStripTiles, int FORM, bool CYC>
 __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout &out, const double *s_tab,
                                              const uint32_t *s_pal, double coord_lane, uint32_t tile0, uint32_t row0,
                                              uint32_t lane) {
+    static_assert(!(CYC && FORM == 0), "the periodicity check lives in the scaled loops");
     constexpr uint32_t P = kStripTiles * 64;
     const ColourConsts cc = make_colour_consts(p);
     const bool julia = p.algo == 2;
@@ -653,7 +724,8 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
 
     T a0 = 0, a1 = 0, a2 = 0, a3 = 0; /* FORM 0: re, im, re*re, im*im;  scaled: X, Y, A, B */
     T c0 = 0, c1 = 0;                 /* FORM 0: c.re, c.im;            scaled: 2c.re, 2c.im */
-    uint32_t pid = 0, done = 0, next = 0;
+    T xs = cycle_none<T>(), ys = cycle_none<T>(); /* CYC: this orbit's state after `saved_at` iterations */
+    uint32_t pid = 0, done = 0, next = 0, saved_at = 0;
     bool busy = false;
     unsigned long long count_acc = 0;
 
@@ -677,6 +749,7 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                 } else {
                     a0 = zre + zre, a1 = zim + zim, a2 = a0 * a0, a3 = a1 * a1, c0 = cre + cre, c1 = cim + cim;
                 }
+                if constexpr (CYC) xs = ys = cycle_none<T>(), saved_at = 0; /* the previous pixel's save is not ours */
                 pid = cand;
                 done = 0;
                 busy = true;
@@ -691,7 +764,13 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
         }
 
         /* ---- one episode */
-        const uint32_t n = wave_min_u32(busy ? iterations - done : 0xFFFFFFFFu);
+        /* run until the lane closest to its cap — or, with CYC, to its next save point — gets there */
+        uint32_t until = iterations - done;
+        if constexpr (CYC) {
+            const uint32_t to_save = next_cycle_save(done) - done;
+            until = to_save < until ? to_save : until;
+        }
+        const uint32_t n = wave_min_u32(busy ? until : 0xFFFFFFFFu);
         const uint32_t nbusy = (uint32_t)__builtin_popcountll(busy_mask);
         EpisodeCtl ctl{0u, 0u};
         if (next < P) ctl = EpisodeCtl{nbusy - (nbusy * p.refill_quit16 + 15) / 16, p.refill_minrun};
@@ -700,14 +779,27 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
             if constexpr (FORM == 0)
                 it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
             else
-                it = orbit_scaled_run<T, FORM>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed);
+                it = orbit_scaled_run<T, FORM, CYC>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed, xs, ys);
         }
-
         /* ---- retire the lanes that finished */
         if (busy) {
-            const bool escaped = it < completed;
+            bool cycled = false;
+            if constexpr (CYC) cycled = (it & 0x80000000u) != 0u;
+            const bool escaped = !cycled && it < completed;
             const uint32_t before = done;
-            done += completed;
+            if (cycled) {
+                /* Back, after before + k iterations, at the state it had after saved_at iterations: the
+                 * orbit is periodic with a period dividing d = before + k - saved_at, and no state of
+                 * the cycle escapes (all were visited without escaping).  recursive() would go on to
+                 * the cap; the state there is the one r = (remaining) mod d steps ahead. */
+                const uint32_t k = it & 0x7FFFFFFFu;
+                const uint32_t d = before + k - saved_at;
+                const uint32_t remaining = iterations - (before + k);
+                done = iterations - remaining % d;
+                xs = ys = cycle_none<T>(); /* no second detection: it would only re-derive this */
+            } else {
+                done += completed;
+            }
             if (escaped || done == iterations) {
                 const uint32_t iters = escaped ? before + it : iterations;
                 T fre, fim, fr2, fi2;
@@ -728,16 +820,23 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                     o[1] = rgb[1];
                     o[2] = rgb[2];
                 } else if constexpr (MODE == FR_OUT_ESCAPE) {
-                    const uint64_t k = (uint64_t)r * p.ncols + cx;
+                    const uint64_t kk = (uint64_t)r * p.ncols + cx;
                     if (out.z) {
-                        out.z[2 * k] = zre;
-                        out.z[2 * k + 1] = zim;
+                        out.z[2 * kk] = zre;
+                        out.z[2 * kk + 1] = zim;
                     }
-                    if (out.iters) out.iters[k] = iters;
+                    if (out.iters) out.iters[kk] = iters;
                 } else {
                     count_acc += iters < iterations ? (unsigned long long)iters + 1ull : iterations;
                 }
                 busy = false;
+            }
+        }
+        if constexpr (CYC) {
+            /* a still-running lane that has just reached one of its save points remembers its state */
+            if (busy && done >= kFirstCycleSave && (done & (done - 1)) == 0u && done != saved_at) {
+                xs = a0, ys = a1;
+                saved_at = done;
             }
         }
     }
@@ -748,7 +847,7 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
     }
 }
 
-template <typename T, int MODE, int kStripTiles, int FORM>
+template <typename T, int MODE, int kStripTiles, int FORM, bool CYC>
 __global__ __launch_bounds__(64) void escape_refill_kernel(const fr_kparams p, const fr_kout out) {
     __shared__ double s_tab[(FR_LOG2_N * 3 * 8 > FR_MAX_PALETTE_ENTRIES * 4 ? FR_LOG2_N * 3 * 8 : FR_MAX_PALETTE_ENTRIES * 4) / 8];
     const uint32_t lane = threadIdx.x;
@@ -801,23 +900,23 @@ __global__ __launch_bounds__(64) void escape_refill_kernel(const fr_kparams p, c
         scaled_ok = __ballot(relevant && !lane_ok) == 0ull;
     }
     if (FORM != 0 && scaled_ok)
-        refill_strip<T, MODE, kStripTiles, FORM>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
+        refill_strip<T, MODE, kStripTiles, FORM, CYC>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
     else
-        refill_strip<T, MODE, kStripTiles, 0>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
+        refill_strip<T, MODE, kStripTiles, 0, false>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
 }
 
-template <typename T, int kStripTiles, int FORM>
+template <typename T, int kStripTiles, int FORM, bool CYC>
 hipError_t launch_refill_form(const fr_kparams &p, int mode, const fr_kout &out, dim3 grid, hipStream_t stream) {
     dim3 block(64);
     switch (mode) {
     case FR_OUT_RGB:
-        hipLaunchKernelGGL((escape_refill_kernel<T, FR_OUT_RGB, kStripTiles, FORM>), grid, block, 0, stream, p, out);
+        hipLaunchKernelGGL((escape_refill_kernel<T, FR_OUT_RGB, kStripTiles, FORM, CYC>), grid, block, 0, stream, p, out);
         break;
     case FR_OUT_ESCAPE:
-        hipLaunchKernelGGL((escape_refill_kernel<T, FR_OUT_ESCAPE, kStripTiles, FORM>), grid, block, 0, stream, p, out);
+        hipLaunchKernelGGL((escape_refill_kernel<T, FR_OUT_ESCAPE, kStripTiles, FORM, CYC>), grid, block, 0, stream, p, out);
         break;
     default:
-        hipLaunchKernelGGL((escape_refill_kernel<T, FR_OUT_COUNT, kStripTiles, FORM>), grid, block, 0, stream, p, out);
+        hipLaunchKernelGGL((escape_refill_kernel<T, FR_OUT_COUNT, kStripTiles, FORM, CYC>), grid, block, 0, stream, p, out);
         break;
     }
     return hipGetLastError();
@@ -832,9 +931,11 @@ hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipS
     const uint64_t gz = (row_tiles + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
-    if (p.loop_mode == 4) return launch_refill_form<T, kStripTiles, 4>(p, mode, out, grid, stream);
-    if (p.loop_mode == 2) return launch_refill_form<T, kStripTiles, 2>(p, mode, out, grid, stream);
-    return launch_refill_form<T, kStripTiles, 0>(p, mode, out, grid, stream);
+    if (p.loop_mode == 4 && p.cycle_shortcut) return launch_refill_form<T, kStripTiles, 4, true>(p, mode, out, grid, stream);
+    if (p.loop_mode == 2 && p.cycle_shortcut) return launch_refill_form<T, kStripTiles, 2, true>(p, mode, out, grid, stream);
+    if (p.loop_mode == 4) return launch_refill_form<T, kStripTiles, 4, false>(p, mode, out, grid, stream);
+    if (p.loop_mode == 2) return launch_refill_form<T, kStripTiles, 2, false>(p, mode, out, grid, stream);
+    return launch_refill_form<T, kStripTiles, 0, false>(p, mode, out, grid, stream);
 }
 
 template <typename T, int kStripTiles>
@@ -902,7 +1003,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
-            if (p.algo == 2) return launch_refill<T, 7>(p, mode, out, stream);
+            if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) return launch_refill<T, 7>(p, mode, out, stream);
             return launch_strips<T, 7>(p, mode, out, stream);
         }
         if (tiles >= 65536) return launch_strips<T, 4>(p, mode, out, stream);

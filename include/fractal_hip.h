@@ -188,6 +188,15 @@ int fr_set_tile(int tile);
  * iterations were done.  Does not affect results. */
 int fr_set_refill_policy(int minrun, int quit16);
 
+/* Exact periodicity shortcut, OFF by default.  When on, large images are rendered by the refilling
+ * kernel and an orbit that returns BITWISE to a state it has already visited (the floating-point map
+ * z -> z^2 + c is a deterministic function of the state, so it is then exactly periodic and can never
+ * escape) is fast-forwarded to the iteration cap — (cap - k) mod d further steps — instead of being
+ * iterated there.  Output bytes, escape indices and final positions are identical to the plain loop;
+ * only the work differs, so bench.py's headline is measured with it off and reports the on-number
+ * separately. */
+int fr_set_cycle_shortcut(int enabled);
+
 /* smooth == false renders look the outside colour up in an LDS-staged palette (one entry per
  * escape index, built once per call on the device) when iterations < 1280; 0 disables that and
  * computes the colour per pixel.  Same bytes either way (tests compare them). */
