@@ -266,13 +266,20 @@ int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_ou
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     if (!cfg->smooth && escape_algo && g_palette_enabled.load() && cfg->iterations < FR_MAX_PALETTE_ENTRIES &&
         g_tile.load() <= 9) {
-        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&palette), sizeof(uint32_t) * (cfg->iterations + 1), stream));
-        p.palette = palette;
-        p.palette_entries = cfg->iterations + 1;
-        hipError_t e = fr_launch_palette(p, palette, stream);
-        if (e != hipSuccess) {
-            (void)hipFreeAsync(palette, stream);
-            return fail_hip(e, "fr_launch_palette");
+        /* no stream-ordered allocator on this device/runtime: not an error, the colour is simply
+         * computed per pixel (same bytes) */
+        if (hipMallocAsync(reinterpret_cast<void **>(&palette), sizeof(uint32_t) * (cfg->iterations + 1), stream) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            palette = nullptr;
+        } else {
+            p.palette = palette;
+            p.palette_entries = cfg->iterations + 1;
+            hipError_t e = fr_launch_palette(p, palette, stream);
+            if (e != hipSuccess) {
+                (void)hipFreeAsync(palette, stream);
+                return fail_hip(e, "fr_launch_palette");
+            }
         }
     }
     struct PaletteGuard {
