@@ -162,6 +162,13 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.sec[0] = cfg->secondary_color.r;
     p.sec[1] = cfg->secondary_color.g;
     p.sec[2] = cfg->secondary_color.b;
+    for (int k = 0; k < 3; k++) {
+        p.prim_f[k] = (double)p.prim[k];
+        p.sec_f[k] = (double)p.sec[k];
+    }
+    p.iterations_f64 = (double)cfg->iterations;
+    const uint32_t n = cfg->iterations;
+    p.inv_iterations = (n != 0 && (n & (n - 1)) == 0) ? 1.0 / (double)n : 0.0; /* exact: n = 2^k */
     p.ncols = cfg->width;
     p.nrows = 0;
     p.x_first = 0;

@@ -20,6 +20,11 @@ struct fr_kparams {
     double julia_re, julia_im;
     uint32_t inside, smooth;
     uint32_t prim[3], sec[3]; /* stored r, g, b fields of primary_color / secondary_color */
+    /* colour-map constants prepared by the host so that they arrive as scalars instead of being
+     * converted by every wave: the colour fields and config.iterations as f64 (exact), and the exact
+     * reciprocal of iterations when it is a power of two (x / 2^k == x * 2^-k), else 0 */
+    double prim_f[3], sec_f[3];
+    double iterations_f64, inv_iterations;
     /* local grid: ncols x nrows pixels; local (cx, r) is image pixel
      *   x = x_first + cx * x_stride
      *   y = y_first + (r / block_rows) * y_stride + r % block_rows                     */

@@ -42,21 +42,17 @@ __device__ __forceinline__ ColourConsts make_colour_consts(const fr_kparams &p) 
     ColourConsts c;
     c.stable_limit = p.stable_limit;
     c.exposure = p.exposure;
-    c.iterations_f64 = (double)p.iterations;
-    const uint32_t n = p.iterations;
-    /* x / 2^k == x * 2^-k for every x (one exact real quotient, rounded once either way) */
-    c.inv_iterations = (n != 0 && (n & (n - 1)) == 0) ? 1.0 / (double)n : 0.0;
+    c.iterations_f64 = p.iterations_f64;
+    c.inv_iterations = p.inv_iterations;
     c.inside = p.inside;
     c.smooth = p.smooth;
     for (int k = 0; k < 3; k++) {
-        c.prim[k] = (double)p.prim[k];
-        c.sec[k] = (double)p.sec[k];
+        c.prim[k] = p.prim_f[k];
+        c.sec[k] = p.sec_f[k];
     }
     return c;
 }
 
-/* color_multiply (calc/src/lib.rs:133-139): RGB::new(r*m, g*m, b*m) with new's (r, b, g)
- * parameter order, i.e. stored {r: r*m, g: b*m, b: g*m}; bytes are emitted r, g, b. */
 /* Rust's `f64 as u8` (truncate, saturate, NaN -> 0) in two instructions: v_cvt_u32_f64 truncates
  * toward zero, saturates out-of-range inputs (negative -> 0, huge / +inf -> 0xFFFFFFFF) and maps
  * NaN to 0; the min brings it to u8 range.  (Inline asm because a plain C cast of an out-of-range
