@@ -344,7 +344,20 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     EQ " vcc, %[Y], %[Ys]\n"                       \
     "s_and_b64 %[scyc], %[scyc], vcc\n"            \
     "s_cbranch_scc1 .Lcyc" TAG "_%=\n"             \
-    ".Lcyccont" TAG "_%=:\n"
+    ".Lcyccont" TAG "_%=:\n"                       \
+    "s_cmp_ge_u32 %[si], %[snext]\n"               \
+    "s_cbranch_scc1 .Lsave" TAG "_%=\n"            \
+    ".Lsavecont" TAG "_%=:\n"
+
+/* Brent's schedule inside the run: when the run's iteration count passes 32, 64, 128, ... every
+ * running lane remembers its state and the count it was taken at. */
+#define FR_SC_CYC_SAVE(MOV, TAG)                   \
+    ".Lsave" TAG "_%=:\n"                          \
+    MOV " %[Xs], %[X]\n"                           \
+    MOV " %[Ys], %[Y]\n"                           \
+    "v_mov_b32 %[vsaved], %[si]\n"                 \
+    "s_lshl_b32 %[snext], %[snext], 1\n"           \
+    "s_branch .Lsavecont" TAG "_%=\n"
 
 #define FR_SC_CYC_HANDLER(TAG)                     \
     ".Lcyc" TAG "_%=:\n"                           \
@@ -374,10 +387,12 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
               FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"), CYC_F, CYC_S, CYC_H)
 #define FR_SC_ASM_M4(SFX) FR_SC_ASM_M4_(SFX, "", "", "")
 #define FR_SC_ASM_M2(SFX) FR_SC_ASM_M2_(SFX, "", "", "")
-#define FR_SC_ASM_M4_CYC(SFX, EQ) \
-    FR_SC_ASM_M4_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S"))
-#define FR_SC_ASM_M2_CYC(SFX, EQ) \
-    FR_SC_ASM_M2_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S"))
+#define FR_SC_CYC_HANDLERS(MOV) \
+    FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S") FR_SC_CYC_SAVE(MOV, "F") FR_SC_CYC_SAVE(MOV, "S")
+#define FR_SC_ASM_M4_CYC(SFX, EQ, MOV) \
+    FR_SC_ASM_M4_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLERS(MOV))
+#define FR_SC_ASM_M2_CYC(SFX, EQ, MOV) \
+    FR_SC_ASM_M2_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLERS(MOV))
 
 template <typename T>
 struct ScalableRange;
@@ -411,20 +426,29 @@ __device__ __forceinline__ bool lane_is_scalable(T re0, T im0, T cre, T cim) {
 template <typename T, int M, bool CYC>
 __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, T &Y, T &A, T &B, T c2re, T c2im,
                                                      T squared, T skip_t, EpisodeCtl ctl, uint32_t &completed,
-                                                     T Xs = T(0), T Ys = T(0)) {
+                                                     T *pXs = nullptr, T *pYs = nullptr,
+                                                     uint32_t *saved_index = nullptr) {
     uint32_t it;
     T t, q;
+    T Xs = CYC ? *pXs : T(0), Ys = CYC ? *pYs : T(0);
+    uint32_t vsaved = 0xFFFFFFFFu; /* CYC: the run's iteration count at this lane's latest save, if any */
+    uint32_t snext = 32u;          /* CYC: next save point of Brent's schedule within this run */
     unsigned long long sorig, sprev, sdiff, scyc;
     uint32_t si, stmp, nrem, scnt;
     const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
     const uint32_t thr = __builtin_amdgcn_readfirstlane(ctl.thr), minrun = __builtin_amdgcn_readfirstlane(ctl.minrun);
     const T lim4_v = (T)4 * squared, t4_v = (T)4 * skip_t;
-#define FR_SC_OPERANDS                                                                                          \
-    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [it] "=&v"(it), [t] "=&v"(t), [q] "=&v"(q),           \
-      [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),     \
-      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt), [scyc] "=&s"(scyc)                                                \
-    : [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n), [thr] "s"(thr),     \
-      [minrun] "s"(minrun), [Xs] "v"(Xs), [Ys] "v"(Ys)                                                          \
+#define FR_SC_OUTPUTS                                                                                           \
+    [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [it] "=&v"(it), [t] "=&v"(t), [q] "=&v"(q),             \
+        [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),   \
+        [nrem] "=&s"(nrem), [scnt] "=&s"(scnt)
+#define FR_SC_INPUTS                                                                                            \
+    [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n), [thr] "s"(thr),       \
+        [minrun] "s"(minrun)
+#define FR_SC_OPERANDS : FR_SC_OUTPUTS : FR_SC_INPUTS : "vcc", "scc"
+#define FR_SC_OPERANDS_CYC                                                                                      \
+    : FR_SC_OUTPUTS, [scyc] "=&s"(scyc), [Xs] "+v"(Xs), [Ys] "+v"(Ys), [vsaved] "+v"(vsaved), [snext] "+s"(snext) \
+    : FR_SC_INPUTS                                                                                              \
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
         const uint64_t lb = fr_bits_of(lim4_v), tb = fr_bits_of(t4_v);
@@ -433,26 +457,32 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
         const uint64_t t4lim = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)tb) |
                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32);
         if constexpr (M == 4 && CYC)
-            asm volatile(FR_SC_ASM_M4_CYC("f64", "v_cmp_eq_u64") FR_SC_OPERANDS);
+            asm volatile(FR_SC_ASM_M4_CYC("f64", "v_cmp_eq_u64", "v_mov_b64") FR_SC_OPERANDS_CYC);
         else if constexpr (M == 4)
             asm volatile(FR_SC_ASM_M4("f64") FR_SC_OPERANDS);
         else if constexpr (CYC)
-            asm volatile(FR_SC_ASM_M2_CYC("f64", "v_cmp_eq_u64") FR_SC_OPERANDS);
+            asm volatile(FR_SC_ASM_M2_CYC("f64", "v_cmp_eq_u64", "v_mov_b64") FR_SC_OPERANDS_CYC);
         else
             asm volatile(FR_SC_ASM_M2("f64") FR_SC_OPERANDS);
     } else {
         const uint32_t lim4 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, lim4_v));
         const uint32_t t4lim = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, t4_v));
         if constexpr (M == 4 && CYC)
-            asm volatile(FR_SC_ASM_M4_CYC("f32", "v_cmp_eq_u32") FR_SC_OPERANDS);
+            asm volatile(FR_SC_ASM_M4_CYC("f32", "v_cmp_eq_u32", "v_mov_b32") FR_SC_OPERANDS_CYC);
         else if constexpr (M == 4)
             asm volatile(FR_SC_ASM_M4("f32") FR_SC_OPERANDS);
         else if constexpr (CYC)
-            asm volatile(FR_SC_ASM_M2_CYC("f32", "v_cmp_eq_u32") FR_SC_OPERANDS);
+            asm volatile(FR_SC_ASM_M2_CYC("f32", "v_cmp_eq_u32", "v_mov_b32") FR_SC_OPERANDS_CYC);
         else
             asm volatile(FR_SC_ASM_M2("f32") FR_SC_OPERANDS);
     }
     (void)scyc;
+    (void)snext;
+    if constexpr (CYC) {
+        *pXs = Xs;
+        *pYs = Ys;
+        *saved_index = vsaved;
+    }
     completed = si;
     return it;
 }
@@ -686,17 +716,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
-/* Periodicity check, Brent's schedule per pixel: a lane saves its orbit state when its own iteration
- * count reaches 32, 64, 128, ... (episodes are cut to end exactly there) and compares against the last
- * save at every block end.  The first save is late enough that pixels which escape within a few
- * dozen iterations never pay for an extra episode boundary. */
-constexpr uint32_t kFirstCycleSave = 32;
-
-__device__ __forceinline__ uint32_t next_cycle_save(uint32_t done) {
-    if (done < kFirstCycleSave) return kFirstCycleSave;
-    if (done >= (1u << 30)) return 0xFFFFFFFFu;
-    return 1u << (32 - __builtin_clz(done)); /* the next power of two above `done` */
-}
+/* Periodicity check: Brent's schedule runs inside orbit_scaled_run (a save when a run's iteration
+ * count passes 32, 64, 128, ...; every run restarts the schedule, which keeps it valid — any earlier
+ * state of the same orbit will do — and gives freshly refilled pixels their first save after 32 of
+ * their own iterations); the lane compares against its latest save at every block end. */
 
 template <typename T>
 __device__ __forceinline__ T cycle_none() { /* a state no orbit passes through: NaN bits */
@@ -760,22 +783,18 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
         }
 
         /* ---- one episode */
-        /* run until the lane closest to its cap — or, with CYC, to its next save point — gets there */
-        uint32_t until = iterations - done;
-        if constexpr (CYC) {
-            const uint32_t to_save = next_cycle_save(done) - done;
-            until = to_save < until ? to_save : until;
-        }
-        const uint32_t n = wave_min_u32(busy ? until : 0xFFFFFFFFu);
+        /* run until the lane closest to its cap gets there */
+        const uint32_t n = wave_min_u32(busy ? iterations - done : 0xFFFFFFFFu);
         const uint32_t nbusy = (uint32_t)__builtin_popcountll(busy_mask);
         EpisodeCtl ctl{0u, 0u};
         if (next < P) ctl = EpisodeCtl{nbusy - (nbusy * p.refill_quit16 + 15) / 16, p.refill_minrun};
-        uint32_t it = 0, completed = 0;
+        uint32_t it = 0, completed = 0, saved_index = 0xFFFFFFFFu;
         if (busy) {
             if constexpr (FORM == 0)
                 it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
             else
-                it = orbit_scaled_run<T, FORM, CYC>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed, xs, ys);
+                it = orbit_scaled_run<T, FORM, CYC>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed, &xs, &ys,
+                                                    &saved_index);
         }
         /* ---- retire the lanes that finished */
         if (busy) {
@@ -783,6 +802,10 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
             if constexpr (CYC) cycled = (it & 0x80000000u) != 0u;
             const bool escaped = !cycled && it < completed;
             const uint32_t before = done;
+            if constexpr (CYC) {
+                /* the run saved this lane's state (xs, ys) after `saved_index` of its iterations */
+                if (saved_index != 0xFFFFFFFFu) saved_at = before + saved_index;
+            }
             if (cycled) {
                 /* Back, after before + k iterations, at the state it had after saved_at iterations: the
                  * orbit is periodic with a period dividing d = before + k - saved_at, and no state of
@@ -826,13 +849,6 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                     count_acc += iters < iterations ? (unsigned long long)iters + 1ull : iterations;
                 }
                 busy = false;
-            }
-        }
-        if constexpr (CYC) {
-            /* a still-running lane that has just reached one of its save points remembers its state */
-            if (busy && done >= kFirstCycleSave && (done & (done - 1)) == 0u && done != saved_at) {
-                xs = a0, ys = a1;
-                saved_at = done;
             }
         }
     }
