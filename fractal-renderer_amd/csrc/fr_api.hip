@@ -182,6 +182,40 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.cycle_shortcut = (g_cycle_shortcut.load() && cfg->iterations < (1u << 30)) ? 1u : 0u;
 }
 
+/* Palette scratch for smooth == false renders: a small ring of device buffers owned by the library
+ * (no allocation on the render path, usable from any stream).  A slot is handed out only after the
+ * event recorded behind its last user has completed. */
+struct PaletteSlot {
+    uint32_t *dev = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false; /* `done` was recorded and not yet waited for */
+    std::atomic<bool> busy{false};
+};
+constexpr int kPaletteSlots = 16;
+PaletteSlot g_palette_slots[kPaletteSlots];
+std::mutex g_palette_mu;
+unsigned g_palette_next = 0;
+
+int acquire_palette_slot(PaletteSlot **out) {
+    std::lock_guard<std::mutex> lk(g_palette_mu);
+    for (int tries = 0; tries < kPaletteSlots; tries++) {
+        PaletteSlot &s = g_palette_slots[g_palette_next++ % kPaletteSlots];
+        if (s.busy.load()) continue; /* another thread is between acquire and its event record */
+        if (!s.dev) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * FR_MAX_PALETTE_ENTRIES));
+            HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+        if (s.pending) {
+            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if 16 renders are in flight */
+            s.pending = false;
+        }
+        s.busy.store(true);
+        *out = &s;
+        return FR_OK;
+    }
+    return fail(FR_ERR_HIP, "no palette slot available");
+}
+
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
  * (the kernels compute every coordinate themselves). */
 double host_coord(double coord, double max, double offset, double pos, double scale) {
@@ -267,35 +301,32 @@ int check_precision(int precision) {
 int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_out, hipStream_t stream) {
     plan_loop(cfg, precision, p);
     /* smooth == false: the outside colour is a function of the escape index alone, so build the
-     * (iterations + 1)-entry palette once (stream-ordered scratch) and let every workgroup stage it
+     * (iterations + 1)-entry palette once (into a library-owned slot) and let every workgroup stage it
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
-    uint32_t *palette = nullptr;
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
+    PaletteSlot *slot = nullptr;
     if (!cfg->smooth && escape_algo && g_palette_enabled.load() && cfg->iterations < FR_MAX_PALETTE_ENTRIES &&
         g_tile.load() <= 9) {
-        /* no stream-ordered allocator on this device/runtime: not an error, the colour is simply
-         * computed per pixel (same bytes) */
-        if (hipMallocAsync(reinterpret_cast<void **>(&palette), sizeof(uint32_t) * (cfg->iterations + 1), stream) !=
-            hipSuccess) {
-            (void)hipGetLastError();
-            palette = nullptr;
-        } else {
-            p.palette = palette;
-            p.palette_entries = cfg->iterations + 1;
-            hipError_t e = fr_launch_palette(p, palette, stream);
-            if (e != hipSuccess) {
-                (void)hipFreeAsync(palette, stream);
-                return fail_hip(e, "fr_launch_palette");
-            }
+        int rc = acquire_palette_slot(&slot);
+        if (rc != FR_OK) return rc;
+        p.palette = slot->dev;
+        p.palette_entries = cfg->iterations + 1;
+        hipError_t e = fr_launch_palette(p, slot->dev, stream);
+        if (e != hipSuccess) {
+            slot->busy.store(false);
+            return fail_hip(e, "fr_launch_palette");
         }
     }
-    struct PaletteGuard {
-        uint32_t *ptr;
+    /* the slot may be reused once everything enqueued so far on `stream` has run */
+    struct SlotGuard {
+        PaletteSlot *slot;
         hipStream_t stream;
-        ~PaletteGuard() {
-            if (ptr) (void)hipFreeAsync(ptr, stream); /* stream-ordered: after the render kernel */
+        ~SlotGuard() {
+            if (!slot) return;
+            slot->pending = hipEventRecord(slot->done, stream) == hipSuccess;
+            slot->busy.store(false);
         }
-    } guard{palette, stream};
+    } guard{slot, stream};
     fr_kout out{};
     out.rgb = static_cast<uint8_t *>(d_out);
     Profiling &pr = tl_prof;
@@ -349,6 +380,17 @@ int fr_shutdown(void) {
         *s = Scratch();
     }
     release_streams_locked();
+    {
+        std::lock_guard<std::mutex> pl(g_palette_mu);
+        for (PaletteSlot &ps : g_palette_slots) {
+            if (ps.done) (void)hipEventDestroy(ps.done);
+            if (ps.dev) (void)hipFree(ps.dev);
+            ps.dev = nullptr;
+            ps.done = nullptr;
+            ps.pending = false;
+            ps.busy.store(false);
+        }
+    }
     g.inited = false;
     return FR_OK;
 }

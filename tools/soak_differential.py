@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""One-off soak: many more seeded random Configs than the test suite runs, every kernel variant,
+loop form, palette and shortcut setting, against the oracle.  python tools/soak_differential.py N"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+import test_gpu_parity as T  # noqa: E402
+import fractal_renderer_amd as fr  # noqa: E402
+from fractal_renderer_amd import _native  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+fr.init(0)
+lib = _native.load()
+t0 = time.time()
+bad = 0
+for seed in range(n):
+    rng = np.random.default_rng(50_000 + seed)
+    ocfg = T._random_config(rng)
+    if rng.random() < 0.3:  # bigger and deeper now and then
+        ocfg.width, ocfg.height = int(rng.integers(300, 700)), int(rng.integers(200, 500))
+        ocfg.iterations = int(rng.choice([500, 1024, 2000, 4100]))
+    cfg = fr.Config.from_buffer_copy(bytes(ocfg))
+    f32 = rng.random() < 0.35
+    op, fp = (O.F32, fr.Precision.F32) if f32 else (O.F64, fr.Precision.F64)
+    knobs = (int(rng.choice([0, 1, 2, 4, 8, 9, 9, 808, 1604, 3202, 6401])), int(rng.choice([-1, -1, 0, 2, 4])),
+             int(rng.random() < 0.7), int(rng.random() < 0.5))
+    lib.fr_set_tile(knobs[0]); lib.fr_set_loop_mode(knobs[1]); lib.fr_set_palette(knobs[2]); lib.fr_set_cycle_shortcut(knobs[3])
+    z, it = fr.escape_rows(cfg, precision=fp)
+    wz, wit = O.escape_rows(ocfg, op)
+    img, want = fr.get_image(cfg, fp), T.oracle_image(ocfg, op)
+    checks = dict(iters=np.array_equal(it, wit), z=T.same_f64(z, wz), image=np.array_equal(img, want),
+                  count=fr.count_iterations(cfg, precision=fp)[0] == O.count_iterations(ocfg, op))
+    if not all(checks.values()):
+        bad += 1
+        print("MISMATCH seed", seed, knobs, "f32" if f32 else "f64", checks, bytes(ocfg).hex(), flush=True)
+        if not checks["image"]:
+            d = np.argwhere((img != want).any(axis=2))
+            print("   image: %d px differ of %d; first (x,y)=%s gpu %s oracle %s iters %d; again equal: %s" % (
+                len(d), img.shape[0] * img.shape[1], (d[0][1], d[0][0]), img[d[0][0], d[0][1]], want[d[0][0], d[0][1]],
+                it[d[0][0], d[0][1]], np.array_equal(fr.get_image(cfg, fp), want)), flush=True)
+    if seed % 50 == 49:
+        print("%d configs, %d mismatches, %.0f s" % (seed + 1, bad, time.time() - t0), flush=True)
+print("done: %d configs, %d mismatches" % (n, bad))
+sys.exit(1 if bad else 0)
