@@ -78,6 +78,53 @@ int fail_hip(hipError_t e, const char *what) {
         if (e_ != hipSuccess) return fail_hip(e_, #expr);     \
     } while (0)
 
+/* Palette scratch for smooth == false renders: a small ring of device buffers owned by the library
+ * (no allocation on the render path, usable from any stream).  A slot is handed out only after the
+ * event recorded behind its last user has completed. */
+struct PaletteSlot {
+    uint32_t *dev = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false; /* `done` was recorded and not yet waited for */
+    std::atomic<bool> busy{false};
+};
+constexpr int kPaletteSlots = 16;
+PaletteSlot g_palette_slots[kPaletteSlots];
+std::mutex g_palette_mu;
+unsigned g_palette_next = 0;
+
+int acquire_palette_slot(PaletteSlot **out) {
+    std::lock_guard<std::mutex> lk(g_palette_mu);
+    for (int tries = 0; tries < kPaletteSlots; tries++) {
+        PaletteSlot &s = g_palette_slots[g_palette_next++ % kPaletteSlots];
+        if (s.busy.load()) continue; /* another thread is between acquire and its event record */
+        if (!s.dev) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * FR_MAX_PALETTE_ENTRIES));
+            HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+        if (s.pending) {
+            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if 16 renders are in flight */
+            s.pending = false;
+        }
+        s.busy.store(true);
+        *out = &s;
+        return FR_OK;
+    }
+    return fail(FR_ERR_HIP, "no palette slot available");
+}
+
+/* called with g.mu held, when the library leaves a device */
+void release_palette_slots() {
+    std::lock_guard<std::mutex> pl(g_palette_mu);
+    for (PaletteSlot &ps : g_palette_slots) {
+        if (ps.done) (void)hipEventDestroy(ps.done);
+        if (ps.dev) (void)hipFree(ps.dev);
+        ps.dev = nullptr;
+        ps.done = nullptr;
+        ps.pending = false;
+        ps.busy.store(false);
+    }
+}
+
 /* caller holds g.mu */
 void release_streams_locked() {
     for (hipEvent_t e : g.band_done) (void)hipEventDestroy(e);
@@ -107,6 +154,7 @@ int init_locked(int device) {
             *s = Scratch();
         }
         release_streams_locked();
+        release_palette_slots();
         g.inited = false;
     }
     HIP_TRY(hipSetDevice(device));
@@ -180,40 +228,6 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.refill_quit16 = (uint32_t)g_refill_quit16.load();
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (g_cycle_shortcut.load() && cfg->iterations < (1u << 30)) ? 1u : 0u;
-}
-
-/* Palette scratch for smooth == false renders: a small ring of device buffers owned by the library
- * (no allocation on the render path, usable from any stream).  A slot is handed out only after the
- * event recorded behind its last user has completed. */
-struct PaletteSlot {
-    uint32_t *dev = nullptr;
-    hipEvent_t done = nullptr;
-    bool pending = false; /* `done` was recorded and not yet waited for */
-    std::atomic<bool> busy{false};
-};
-constexpr int kPaletteSlots = 16;
-PaletteSlot g_palette_slots[kPaletteSlots];
-std::mutex g_palette_mu;
-unsigned g_palette_next = 0;
-
-int acquire_palette_slot(PaletteSlot **out) {
-    std::lock_guard<std::mutex> lk(g_palette_mu);
-    for (int tries = 0; tries < kPaletteSlots; tries++) {
-        PaletteSlot &s = g_palette_slots[g_palette_next++ % kPaletteSlots];
-        if (s.busy.load()) continue; /* another thread is between acquire and its event record */
-        if (!s.dev) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * FR_MAX_PALETTE_ENTRIES));
-            HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        }
-        if (s.pending) {
-            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if 16 renders are in flight */
-            s.pending = false;
-        }
-        s.busy.store(true);
-        *out = &s;
-        return FR_OK;
-    }
-    return fail(FR_ERR_HIP, "no palette slot available");
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
@@ -380,17 +394,7 @@ int fr_shutdown(void) {
         *s = Scratch();
     }
     release_streams_locked();
-    {
-        std::lock_guard<std::mutex> pl(g_palette_mu);
-        for (PaletteSlot &ps : g_palette_slots) {
-            if (ps.done) (void)hipEventDestroy(ps.done);
-            if (ps.dev) (void)hipFree(ps.dev);
-            ps.dev = nullptr;
-            ps.done = nullptr;
-            ps.pending = false;
-            ps.busy.store(false);
-        }
-    }
+    release_palette_slots();
     g.inited = false;
     return FR_OK;
 }

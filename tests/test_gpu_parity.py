@@ -362,6 +362,41 @@ def test_exact_cycle_shortcut_is_bit_identical(fr, view, prec):
         lib.fr_set_tile(0)
 
 
+def test_palette_path_is_stable_over_a_long_call_history(fr):
+    """Regression for an intermittent failure the soak (tools/soak_differential.py) found when the
+    palette lived in stream-ordered (hipMallocAsync) memory: after hundreds of mixed calls a palette
+    was read back as zeros.  700 mixed configurations, palette on vs off, must agree every time."""
+    from fractal_renderer_amd import _native
+
+    lib = _native.load()
+    bad = []
+    try:
+        for seed in range(700):
+            rng = np.random.default_rng(50_000 + seed)
+            ocfg = _random_config(rng)
+            if rng.random() < 0.3:
+                ocfg.width, ocfg.height = int(rng.integers(300, 700)), int(rng.integers(200, 500))
+                ocfg.iterations = int(rng.choice([500, 1024, 2000, 4100]))
+            cfg = to_fr(fr, ocfg)
+            fp = fr.Precision.F32 if rng.random() < 0.35 else fr.Precision.F64
+            lib.fr_set_tile(int(rng.choice([0, 1, 2, 4, 8, 9, 9, 808, 1604, 3202, 6401])))
+            lib.fr_set_loop_mode(int(rng.choice([-1, -1, 0, 2, 4])))
+            lib.fr_set_palette(1)
+            lib.fr_set_cycle_shortcut(int(rng.random() < 0.5))
+            fr.escape_rows(cfg, precision=fp)
+            a = fr.get_image(cfg, fp)
+            fr.count_iterations(cfg, precision=fp)
+            lib.fr_set_palette(0)
+            if not np.array_equal(a, fr.get_image(cfg, fp)):
+                bad.append(seed)
+    finally:
+        lib.fr_set_tile(0)
+        lib.fr_set_loop_mode(-1)
+        lib.fr_set_palette(1)
+        lib.fr_set_cycle_shortcut(0)
+    assert not bad, bad
+
+
 TINY_CASES = {
     # orbits whose products pass through the subnormal range: the scaled loop must not be used
     "julia_c_zero": dict(algo=O.JULIA, julia_set=(0.0, 0.0), iterations=40),
