@@ -603,6 +603,48 @@ def test_full_size_c5_65536_squared_on_one_device(fr):
     del img
 
 
+def test_device_pointer_api_from_concurrent_threads_and_streams(fr):
+    """fr_render_rows_rgb8_device is lock-free: several host threads, each on its own HIP stream
+    (torch streams used only as plumbing), render different configs at once — smooth and palette
+    paths mixed — into their own device buffers; every result must equal the serial render."""
+    import threading
+
+    import torch
+
+    from fractal_renderer_amd import partition as P
+
+    ocfgs = [O.cli_config(320, 200, iterations=300), O.cli_config(200, 320, iterations=150, smooth=0),
+             O.cli_config(256, 256, O.JULIA, julia_set=(-0.8, 0.156), iterations=400),
+             O.cli_config(400, 120, iterations=90, smooth=0, inside=0)]
+    cfgs = [to_fr(fr, c) for c in ocfgs]
+    want = [fr.get_image(c) for c in cfgs]
+    errs = []
+
+    def work(i):
+        try:
+            cfg = cfgs[i]
+            dev = torch.device("cuda", 0)
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                out = torch.empty(cfg.height * cfg.width * 3, dtype=torch.uint8, device=dev)
+            for _ in range(25):
+                with torch.cuda.stream(stream):
+                    out.zero_()  # same stream as the render: ordered before it
+                    P.render_rows_hip(cfg, 0, 0, cfg.height, out, stream.cuda_stream)
+                stream.synchronize()
+                got = out.cpu().numpy().reshape(cfg.height, cfg.width, 3)
+                if not np.array_equal(got, want[i]):
+                    errs.append("thread %d: mismatch" % i)
+                    return
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cfgs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+
+
 def test_bench_smoke_small():
     """bench.py end to end on a small image: torch-first import order, HIP-event timing, roofline and
     cpu_baseline objects, and its own GPU-vs-CPU byte comparison."""
