@@ -581,6 +581,47 @@ def test_full_size_c2_sampled_against_oracle(fr):
     assert np.array_equal(band, img[8000:8192])
 
 
+def test_full_size_c4_julia_f32_sampled_against_oracle(fr):
+    """C4 (Julia c = -0.8+0.156i, 16384^2, 4096 iterations, f32) through the default dispatch (the
+    refilling kernel at this size): every 16th pixel and the exact iteration sum against the oracle."""
+    ocfg = O.cli_config(16384, 16384, O.JULIA, julia_set=(-0.8, 0.156), iterations=4096)
+    cfg = to_fr(fr, ocfg)
+    img = fr.get_image(cfg, fr.Precision.F32)
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        total, npx, want = O.sample_image(ocfg, 16, 16, O.F32)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+    assert np.array_equal(img[::16, ::16], want)
+    assert fr.count_iterations(cfg, sx=16, sy=16, precision=fr.Precision.F32) == (total, npx)
+    # the Julia set of a c is symmetric under z -> -z: the image equals itself rotated by 180 degrees
+    # about the centre pixel grid point (x, y) -> (W - x, H - y) for x, y >= 1
+    assert np.array_equal(img[1:, 1:], img[:0:-1, :0:-1])
+
+
+def test_full_size_c3_deep_zoom_sampled_and_shortcut(fr):
+    """C3 (16384^2, zoom 10^6, 65536 iterations, f64): every 64th pixel against the oracle, and the
+    exact-periodicity shortcut must reproduce the plain render byte for byte at full size."""
+    from fractal_renderer_amd import _native
+
+    ocfg = O.cli_config(16384, 16384, iterations=65536, scale=(1e6, 1e6), pos=(-0.7436447860, 0.1318252536))
+    cfg = to_fr(fr, ocfg)
+    img = fr.get_image(cfg)
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        total, npx, want = O.sample_image(ocfg, 64, 64)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+    assert np.array_equal(img[::64, ::64], want)
+    assert fr.count_iterations(cfg, sx=64, sy=64) == (total, npx)
+    lib = _native.load()
+    try:
+        _native.check(lib.fr_set_cycle_shortcut(1))
+        assert np.array_equal(fr.get_image(cfg), img)
+    finally:
+        lib.fr_set_cycle_shortcut(0)
+
+
 def test_full_size_c5_65536_squared_on_one_device(fr):
     """BASELINE C5's image (65536^2 = 2^32 pixels, 12.9 GB) rendered whole on ONE device: every
     index is past 32 bits.  Every 64th pixel in x and y against the oracle, the exact iteration sum on
