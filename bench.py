@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--refill", default="", help="tuning: minrun,quit16 of the refilling kernel")
     ap.add_argument("--cycle-shortcut", action="store_true",
                     help="measure with the exact periodicity shortcut on (never the headline: it skips iterations)")
+    ap.add_argument("--force-blocks", action="store_true",
+                    help="N=1 only: render block by block like a rank of an N>1 run does (tuning of --block-rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores available)")
     return ap.parse_args()
@@ -145,7 +147,7 @@ def main():
     cfg = make_config(fr, args, edge)
     row_bytes = 3 * cfg.width
     B = args.block_rows
-    renderer = P.DistributedRenderer(cfg, prec, B, device=device)
+    renderer = P.DistributedRenderer(cfg, prec, B, device=device, force_blocks=args.force_blocks)
     stream = torch.cuda.current_stream(device)
 
     kernel_ms = []
@@ -154,7 +156,7 @@ def main():
         # N = 1: one launch renders the whole image in place; N > 1: one launch per owned row block,
         # each block sent to rank 0 while the next one renders (partition.DistributedRenderer)
         img = renderer.render()
-        if record and world == 1:
+        if record and world == 1 and not args.force_blocks:
             ms = C.c_float(0)
             _native.check(lib.fr_last_kernel_ms(C.byref(ms)))  # HIP events on the launch stream
             kernel_ms.append(ms.value)

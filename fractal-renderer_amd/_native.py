@@ -96,6 +96,11 @@ PROTOTYPES = {
         [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
          C.POINTER(C.c_uint64)],
     ),
+    "fr_render_block_cyclic_range_rgb8_device": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+         C.c_void_p, C.POINTER(C.c_uint64)],
+    ),
     "fr_render_block_cyclic_rgb8": (
         C.c_int,
         [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,

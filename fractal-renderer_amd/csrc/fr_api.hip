@@ -465,9 +465,10 @@ uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t fir
     return rows;
 }
 
-int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
-                                       uint32_t first_block, uint32_t block_stride, void *d_out, size_t out_len,
-                                       void *hip_stream, uint64_t *rows_written) {
+int fr_render_block_cyclic_range_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
+                                             uint32_t first_block, uint32_t block_stride, uint32_t max_blocks,
+                                             int dest_is_image, void *d_out, size_t out_len, void *hip_stream,
+                                             uint64_t *rows_written) {
     if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
     int rc = check_precision(precision);
     if (rc != FR_OK) return rc;
@@ -475,19 +476,36 @@ int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint
         return fail(FR_ERR_INVALID_ARGUMENT, "block_rows and block_stride must be > 0");
     if ((uint64_t)block_rows * block_stride > 0xFFFFFFFFull)
         return fail(FR_ERR_INVALID_ARGUMENT, "block_rows * block_stride overflows u32");
-    const uint64_t rows = fr_block_cyclic_rows(cfg->height, block_rows, first_block, block_stride);
+    if (dest_is_image && block_rows % 8 != 0)
+        return fail(FR_ERR_INVALID_ARGUMENT, "in-place block-cyclic rendering needs block_rows % 8 == 0");
+    /* rows of blocks first_block, first_block + stride, ... (at most max_blocks of them; 0 = all) */
+    uint64_t rows = 0, blocks = 0;
+    for (uint64_t b = first_block; b * block_rows < cfg->height && (max_blocks == 0 || blocks < max_blocks);
+         b += block_stride, blocks++) {
+        const uint64_t left = cfg->height - b * block_rows;
+        rows += left < block_rows ? left : block_rows;
+    }
     if (rows_written) *rows_written = rows;
-    const size_t need = (size_t)3 * cfg->width * (size_t)rows;
-    if (need == 0) return FR_OK;
+    const size_t need = dest_is_image ? (size_t)3 * cfg->width * (size_t)cfg->height : (size_t)3 * cfg->width * (size_t)rows;
+    if (rows == 0 || cfg->width == 0) return FR_OK;
     if (!d_out) return fail(FR_ERR_INVALID_ARGUMENT, "d_out is NULL");
-    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*rows");
+    if (out_len < need)
+        return fail(FR_ERR_BUFFER_TOO_SMALL, dest_is_image ? "out_len < 3*width*height" : "out_len < 3*width*rows");
     fr_kparams p;
     fill_params(cfg, p);
     p.nrows = (uint32_t)rows;
     p.block_rows = block_rows;
     p.y_first = first_block * block_rows;
     p.y_stride = block_rows * block_stride;
+    p.out_in_place = dest_is_image ? 1u : 0u;
     return render_device(cfg, p, precision, d_out, static_cast<hipStream_t>(hip_stream));
+}
+
+int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
+                                       uint32_t first_block, uint32_t block_stride, void *d_out, size_t out_len,
+                                       void *hip_stream, uint64_t *rows_written) {
+    return fr_render_block_cyclic_range_rgb8_device(cfg, precision, block_rows, first_block, block_stride, 0, 0,
+                                                    d_out, out_len, hip_stream, rows_written);
 }
 
 int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t block_rows, uint32_t first_block,

@@ -31,6 +31,10 @@ struct fr_kparams {
     uint32_t ncols, nrows;
     uint32_t x_first, x_stride;
     uint32_t block_rows, y_first, y_stride;
+    /* RGB output addressing: 0 = packed (local row r at 3*ncols*r), 1 = in place (local row r at its
+     * IMAGE row y: the destination is the whole image).  In place needs block_rows % 8 == 0 so that
+     * an 8-row tile never straddles two blocks. */
+    uint32_t out_in_place;
     /* orbit-loop plan chosen by the host (fr_api.hip: plan_loop): 0 = unscaled loop, escape
      * check every iteration; 4 / 2 = scaled loop, escape check every 4th / 2nd iteration while
      * every live lane of the wave has |z|^2 <= skip_t (see fr_kernels.hip). */

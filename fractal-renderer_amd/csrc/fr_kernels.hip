@@ -530,7 +530,7 @@ __device__ __forceinline__ double coord_to_space(double coord, double max, doubl
 template <typename T, int MODE>
 __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout &out, const double *s_tab,
                                              const uint32_t *s_pal, double sre, double sim, bool valid,
-                                             uint32_t cx, uint32_t r, uint32_t lane) {
+                                             uint32_t cx, uint32_t r, uint32_t lane, uint32_t r_out) {
     double zre = 0.0, zim = 0.0, dist = 0.0;
     uint32_t iters = 0;
     const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
@@ -562,7 +562,7 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
                 const ColourConsts cc = make_colour_consts(p);
                 colour_of(cc, dist, iters, s_tab, s_pal, rgb);
             }
-            uint8_t *o = out.rgb + 3ull * ((uint64_t)r * p.ncols + cx);
+            uint8_t *o = out.rgb + 3ull * ((uint64_t)r_out * p.ncols + cx);
             o[0] = rgb[0];
             o[1] = rgb[1];
             o[2] = rgb[2];
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
     const uint32_t ly = (wave / WX) * TH + lane / TW;
     const uint32_t cx = col0 + lx, r = row0 + ly;
     const bool valid = cx < p.ncols && r < p.nrows;
-    render_pixel<T, MODE>(p, out, s_tab, nullptr, s_re[lx], s_im[ly], valid, cx, r, lane);
+    render_pixel<T, MODE>(p, out, s_tab, nullptr, s_re[lx], s_im[ly], valid, cx, r, lane, r);
 }
 
 /* Default kernel: ONE WAVE PER WORKGROUP renders a horizontal strip of kStripTiles 8x8 tiles
@@ -681,6 +681,11 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
     const double coord_lane = coord_to_space((double)coord_u, height, row_lane ? 0.5 : (width / height) / 2.0,
                                              row_lane ? p.pos_im : p.pos_re, row_lane ? p.scale_im : p.scale_re);
     const double sim = __shfl(coord_lane, 56 + ly, 64);
+    /* where this strip's rows go: packed, or at their image rows (in place; the tile's 8 rows are in
+     * one block because block_rows % 8 == 0, so the map is evaluated once, wave-uniformly) */
+    uint32_t out_row0 = row0;
+    if (p.out_in_place) out_row0 = p.y_first + (row0 / p.block_rows) * p.y_stride + row0 % p.block_rows;
+    const uint32_t r_out = out_row0 + ly;
 
     for (int k = 0; k < kStripTiles; k++) {
         const uint32_t col0 = (tile0 + k) * 8u;
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
         const double sre = __shfl(coord_lane, k * 8 + lx, 64);
         const uint32_t cx = col0 + lx;
         const bool valid = cx < p.ncols && r < p.nrows;
-        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane);
+        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane, r_out);
     }
 }
 
@@ -734,6 +739,8 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                                              const uint32_t *s_pal, double coord_lane, uint32_t tile0, uint32_t row0,
                                              uint32_t lane) {
     static_assert(!(CYC && FORM == 0), "the periodicity check lives in the scaled loops");
+    uint32_t out_row0 = row0; /* packed, or the strip's image row (in place); see escape_strip_kernel */
+    if (p.out_in_place) out_row0 = p.y_first + (row0 / p.block_rows) * p.y_stride + row0 % p.block_rows;
     constexpr uint32_t P = kStripTiles * 64;
     const ColourConsts cc = make_colour_consts(p);
     const bool julia = p.algo == 2;
@@ -834,7 +841,8 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                 if constexpr (MODE == FR_OUT_RGB) {
                     uint8_t rgb[3];
                     colour_of(cc, dist, iters, s_tab, s_pal, rgb);
-                    uint8_t *o = out.rgb + 3ull * ((uint64_t)r * p.ncols + cx);
+                    const uint32_t r_out = out_row0 + ((pid >> 3) & 7u);
+                    uint8_t *o = out.rgb + 3ull * ((uint64_t)r_out * p.ncols + cx);
                     o[0] = rgb[0];
                     o[1] = rgb[1];
                     o[2] = rgb[2];
@@ -998,6 +1006,7 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 
 template <typename T>
 hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream) {
+    if (p.out_in_place && tile > 9) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
         return launch_tile<T, 64, 1, 1, 4>(p, mode, out, stream);

@@ -10,8 +10,9 @@ Gather = point-to-point sends of finished blocks to rank 0 (RCCL over xGMI on a 
 peer -> root transfer rides its own link, so the 7 peers of an 8-GPU node land in parallel).  Round
 k of the schedule is "block k*world + r from every rank r": those blocks are ADJACENT in the image,
 so rank 0 receives every block straight into its final place — no reorder pass — and renders its
-own blocks in place.  Rounds are pipelined: round k is on the wire (communication stream) while
-round k+1 renders (compute stream).
+own blocks in place.  A rank renders several of its blocks per kernel launch ("chunk": big chunks
+first, a geometric tail 4, 2, 1 last) and chunks are pipelined: chunk c is on the wire (communication
+stream) while chunk c+1 renders (two alternating compute streams).
 
 torch is used here only as plumbing (device buffers, streams, torch.distributed = RCCL on ROCm,
 gloo in the CPU tests); the rendering itself goes through the C ABI.
@@ -24,6 +25,27 @@ import torch.distributed as dist
 from . import _native
 
 DEFAULT_BLOCK_ROWS = 256
+N_BLOCK_STREAMS = 2      # chunk kernels alternate between this many streams (measured: 1 stream costs +60 %
+                         # at 256-row launches because nothing covers a kernel's tail; 4 is no better than 2)
+MAX_CHUNK_BLOCKS = 8     # blocks per launch (2048 rows at the default block size: as fast as one launch)
+
+
+def chunk_schedule(nb):
+    """Local block index ranges [j0, j1) a rank renders per launch: big chunks first (launches of
+    >= 1024 rows run at the single-launch rate; 256-row launches measured 17 % slower), then a
+    geometric tail 4, 2, 1 so that the bytes still to be sent when the last kernel ends are one block."""
+    sizes, rem, s = [], nb, 1
+    while rem > 0:
+        t = min(s, rem, MAX_CHUNK_BLOCKS)
+        sizes.append(t)
+        rem -= t
+        s *= 2
+    sizes.reverse()
+    ranges, j = [], 0
+    for t in sizes:
+        ranges.append((j, j + t))
+        j += t
+    return ranges
 
 
 def num_blocks(height, block_rows):
@@ -59,6 +81,19 @@ def render_rows_hip(config, precision, y0, y1, out, stream_ptr):
             C.byref(config), int(precision), y0, y1, out.data_ptr(), out.numel(), stream_ptr
         )
     )
+
+
+def render_chunk_hip(config, precision, block_rows, first_block, block_stride, max_blocks, in_place, out, stream_ptr):
+    """Blocks first_block, first_block + stride, ... (at most max_blocks) in ONE launch: packed into
+    `out`, or — in_place — each row at its place in the whole image whose base is `out`."""
+    rows = C.c_uint64(0)
+    _native.check(
+        _native.load().fr_render_block_cyclic_range_rgb8_device(
+            C.byref(config), int(precision), block_rows, first_block, block_stride, max_blocks, 1 if in_place else 0,
+            out.data_ptr(), out.numel(), stream_ptr, C.byref(rows),
+        )
+    )
+    return rows.value
 
 
 def render_local_hip(config, precision, block_rows, rank, world, out, stream_ptr):
@@ -100,7 +135,7 @@ class DistributedRenderer:
     render_rows(config, precision, y0, y1, out_view)."""
 
     def __init__(self, config, precision=0, block_rows=DEFAULT_BLOCK_ROWS, group=None, device=None,
-                 render_rows=None):
+                 render_rows=None, force_blocks=False):
         self.config = config
         self.precision = int(precision)
         self.block_rows = int(block_rows)
@@ -111,6 +146,7 @@ class DistributedRenderer:
         self.height = config.height
         self.nblocks = num_blocks(self.height, self.block_rows)
         self.cuda = render_rows is None
+        self.force_blocks = bool(force_blocks)  # world == 1: still render block by block (tests, tuning)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.cuda else torch.device("cpu")
         self.device = device
@@ -124,17 +160,22 @@ class DistributedRenderer:
             self.local = torch.empty(max(my * self.row_bytes, 1), dtype=torch.uint8, device=device)
         if self.cuda:
             self.compute_stream = torch.cuda.current_stream(device)
+            # consecutive blocks render on alternating streams so that the tail of one block's kernel
+            # (its last, longest strips) overlaps the start of the next instead of idling the GPU
+            self.block_streams = [self.compute_stream] + [torch.cuda.Stream(device) for _ in range(N_BLOCK_STREAMS - 1)]
             self.comm_stream = torch.cuda.Stream(device) if self.world > 1 else None
         else:
             self.compute_stream = self.comm_stream = None
+            self.block_streams = [None] * N_BLOCK_STREAMS
 
     # -- helpers ---------------------------------------------------------------------------
     def _image_rows(self, y0, y1):
         return self.image[y0 * self.row_bytes : y1 * self.row_bytes]
 
-    def _render(self, y0, y1, out):
+    def _render(self, y0, y1, out, stream=None):
         if self.cuda:
-            render_rows_hip(self.config, self.precision, y0, y1, out, self.compute_stream.cuda_stream)
+            stream = self.compute_stream if stream is None else stream
+            render_rows_hip(self.config, self.precision, y0, y1, out, stream.cuda_stream)
         else:
             self._render_rows(self.config, self.precision, y0, y1, out)
 
@@ -145,49 +186,77 @@ class DistributedRenderer:
         bookkeeping; call torch.cuda.synchronize() (or use the result on the current stream,
         which is made to wait for the gather) before reading."""
         cfg, B, N, r = self.config, self.block_rows, self.world, self.rank
-        if N == 1:
+        if N == 1 and not self.force_blocks:
             # single launch of the whole image, rendered in place
             self._render(0, self.height, self._image_rows(0, self.height))
             return self.image[: self.height * self.row_bytes].view(self.height, cfg.width, 3)
 
         works = []
-        rounds = (self.nblocks + N - 1) // N
         local_off = 0
-        for k in range(rounds):
-            b_mine = k * N + r
-            if b_mine < self.nblocks:
-                y0, y1 = block_range(self.height, B, b_mine)
-                nbytes = (y1 - y0) * self.row_bytes
+        if self.cuda:
+            for st in self.block_streams[1:]:
+                st.wait_stream(self.compute_stream)  # order behind earlier work
+        nb_max = (self.nblocks + N - 1) // N  # local blocks of rank 0, the rank with the most
+        for c, (j0, j1) in enumerate(chunk_schedule(nb_max)):
+            mine = [j * N + r for j in range(j0, j1) if j * N + r < self.nblocks]
+            done_event, sends = None, []
+            if mine:
+                stream = self.block_streams[c % N_BLOCK_STREAMS]
                 if r == 0:
-                    out = self._image_rows(y0, y1)  # rank 0 renders in place
+                    # rank 0 renders every chunk in place
+                    if self.cuda:
+                        render_chunk_hip(cfg, self.precision, B, mine[0], N, len(mine), True, self.image,
+                                         stream.cuda_stream)
+                    else:
+                        for b in mine:
+                            y0, y1 = block_range(self.height, B, b)
+                            self._render(y0, y1, self._image_rows(y0, y1))
                 else:
-                    out = self.local[local_off : local_off + nbytes]
-                    local_off += nbytes
-                self._render(y0, y1, out)
-            else:
-                out = None
-            # hand round k to the communication stream; round k+1 renders meanwhile
+                    rows = sum(block_range(self.height, B, b)[1] - block_range(self.height, B, b)[0] for b in mine)
+                    chunk = self.local[local_off : local_off + rows * self.row_bytes]
+                    if self.cuda:
+                        render_chunk_hip(cfg, self.precision, B, mine[0], N, len(mine), False, chunk, stream.cuda_stream)
+                    off = 0
+                    for b in mine:
+                        y0, y1 = block_range(self.height, B, b)
+                        part = chunk[off : off + (y1 - y0) * self.row_bytes]
+                        if not self.cuda:
+                            self._render(y0, y1, part)
+                        sends.append(part)
+                        off += (y1 - y0) * self.row_bytes
+                    local_off += rows * self.row_bytes
+                if self.cuda:
+                    done_event = torch.cuda.Event()
+                    done_event.record(stream)
+            if N == 1:
+                continue
+            # hand chunk c to the communication stream; chunk c+1 renders meanwhile
             if self.cuda:
-                self.comm_stream.wait_stream(self.compute_stream)
+                if done_event is not None:
+                    self.comm_stream.wait_event(done_event)
                 ctx = torch.cuda.stream(self.comm_stream)
             else:
                 ctx = _NullContext()
             with ctx:
                 if r == 0:
                     ops = []
-                    for src in range(1, N):
-                        b = k * N + src
-                        if b < self.nblocks:
-                            y0, y1 = block_range(self.height, B, b)
-                            ops.append(dist.P2POp(dist.irecv, self._image_rows(y0, y1), src, self.group))
-                    if ops:
-                        works.extend(dist.batch_isend_irecv(ops))
-                elif out is not None:
-                    works.extend(dist.batch_isend_irecv([dist.P2POp(dist.isend, out, 0, self.group)]))
+                    for src in range(1, N):  # per peer, in the peer's own sending order
+                        for j in range(j0, j1):
+                            b = j * N + src
+                            if b < self.nblocks:
+                                y0, y1 = block_range(self.height, B, b)
+                                ops.append(dist.P2POp(dist.irecv, self._image_rows(y0, y1), src, self.group))
+                else:
+                    ops = [dist.P2POp(dist.isend, part, 0, self.group) for part in sends]
+                if ops:
+                    works.extend(dist.batch_isend_irecv(ops))
         for w in works:
             w.wait()  # CUDA: makes the current stream wait for the transfer; gloo: blocks
         if self.cuda:
-            self.compute_stream.wait_stream(self.comm_stream)
+            for st in self.block_streams[1:]:
+                self.compute_stream.wait_stream(st)
+            if self.comm_stream is not None:
+                self.compute_stream.wait_stream(self.comm_stream)
         if r == 0:
             return self.image[: self.height * self.row_bytes].view(self.height, cfg.width, 3)
         return None

@@ -136,6 +136,14 @@ int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0,
 int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
                                        uint32_t first_block, uint32_t block_stride, void *d_out,
                                        size_t out_len, void *hip_stream, uint64_t *rows_written);
+/* The same with two refinements used by the pipelined multi-GPU gather: at most `max_blocks` blocks
+ * (0 = all), and `dest_is_image` != 0 to write every row at its place in the WHOLE image (d_out is
+ * then the image base, out_len >= 3*width*height, block_rows % 8 == 0) instead of packing. */
+int fr_render_block_cyclic_range_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
+                                             uint32_t first_block, uint32_t block_stride, uint32_t max_blocks,
+                                             int dest_is_image, void *d_out, size_t out_len, void *hip_stream,
+                                             uint64_t *rows_written);
+
 /* Same share into a HOST buffer (packed blocks, 3*width*rows bytes). */
 int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t block_rows, uint32_t first_block,
                                 uint32_t block_stride, uint8_t *out, size_t out_len, uint64_t *rows_written);

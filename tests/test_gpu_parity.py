@@ -498,6 +498,51 @@ def test_iteration_cap_extremes(fr):
         assert np.array_equal(fr.get_image(cfg), oracle_image(ocfg)), it
 
 
+@pytest.mark.parametrize("world,block_rows,h", [(1, 8, 193), (2, 16, 193), (3, 8, 200), (8, 8, 193), (4, 64, 1000)])
+def test_chunked_block_cyclic_rendering_packed_and_in_place(fr, world, block_rows, h):
+    """What each rank of the pipelined multi-GPU gather launches (partition.DistributedRenderer): its
+    blocks chunk by chunk, packed (ranks > 0) or straight into the whole image (rank 0) — all logical
+    ranks on one device here; the reassembled image must equal the single render."""
+    import torch
+
+    from fractal_renderer_amd import partition as P
+
+    ocfg = O.cli_config(257, h, iterations=120)
+    cfg = to_fr(fr, ocfg)
+    want = fr.get_image(cfg)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    rb = 3 * cfg.width
+    nblocks = P.num_blocks(h, block_rows)
+    nb_max = (nblocks + world - 1) // world
+    image = torch.zeros(h * rb, dtype=torch.uint8, device=dev)
+    for r in range(world):
+        for (j0, j1) in P.chunk_schedule(nb_max):
+            mine = [j * world + r for j in range(j0, j1) if j * world + r < nblocks]
+            if not mine:
+                continue
+            if r == 0:
+                P.render_chunk_hip(cfg, 0, block_rows, mine[0], world, len(mine), True, image, stream.cuda_stream)
+            else:
+                rows = sum(P.block_range(h, block_rows, b)[1] - P.block_range(h, block_rows, b)[0] for b in mine)
+                chunk = torch.empty(rows * rb, dtype=torch.uint8, device=dev)
+                got_rows = P.render_chunk_hip(cfg, 0, block_rows, mine[0], world, len(mine), False, chunk, stream.cuda_stream)
+                assert got_rows == rows
+                off = 0
+                for b in mine:  # what the P2P receive does on rank 0
+                    y0, y1 = P.block_range(h, block_rows, b)
+                    image[y0 * rb : y1 * rb] = chunk[off : off + (y1 - y0) * rb]
+                    off += (y1 - y0) * rb
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy().reshape(h, cfg.width, 3), want)
+    # and the renderer object itself, block by block on one rank
+    renderer = P.DistributedRenderer(cfg, 0, block_rows, device=dev, force_blocks=True)
+    for _ in range(2):
+        img = renderer.render()
+        torch.cuda.synchronize()
+        assert np.array_equal(img.cpu().numpy(), want)
+
+
 def test_get_recursive_pixel_outside_the_image(fr):
     # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
     ocfg = O.cli_config(64, 48, iterations=80)
