@@ -16,6 +16,7 @@ import fractal_renderer_amd as fr  # noqa: E402
 from fractal_renderer_amd import _native  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+big = len(sys.argv) > 2 and sys.argv[2] == "big"  # large images: default dispatch reaches the 7-tile kernels
 fr.init(0)
 lib = _native.load()
 t0 = time.time()
@@ -26,6 +27,9 @@ for seed in range(n):
     if rng.random() < 0.3:  # bigger and deeper now and then
         ocfg.width, ocfg.height = int(rng.integers(300, 700)), int(rng.integers(200, 500))
         ocfg.iterations = int(rng.choice([500, 1024, 2000, 4100]))
+    if big:
+        ocfg.width, ocfg.height = int(rng.integers(1500, 5000)), int(rng.integers(1500, 5000))
+        ocfg.iterations = int(rng.choice([5, 64, 300, 1024]))
     cfg = fr.Config.from_buffer_copy(bytes(ocfg))
     f32 = rng.random() < 0.35
     op, fp = (O.F32, fr.Precision.F32) if f32 else (O.F64, fr.Precision.F64)
