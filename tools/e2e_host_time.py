@@ -9,7 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fractal_renderer_amd as fr  # noqa: E402
 
 fr.init(0)
-for (w, h, it) in [(750, 500, 50), (3000, 3000, 1024), (16384, 16384, 1024)]:
+for (w, h, it) in [(750, 500, 50), (1500, 1000, 50), (1920, 1080, 400), (3840, 2160, 400), (3000, 3000, 1024),
+                   (16384, 16384, 1024)]:
     cfg = fr.Config.new()
     cfg.width, cfg.height, cfg.iterations = w, h, it
     cfg.pos.re, cfg.exposure = -0.6, 5.0
