@@ -275,10 +275,16 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": traffic,
-                "kernel": "escape_kernel (fused coordinate map + orbit loop + colour map)",
+                "kernel": "escape_strip_kernel<%s, RGB, 7 tiles> (fused coordinate map + orbit loop + colour map)"
+                          % ("double" if args.precision == "f64" else "float"),
                 "algorithmic_flops_per_launch": FLOPS_PER_ITERATION * launch_px_it,
                 "frac_of_attainable_no_fma": (VALU_OPS_PER_ITERATION * launch_px_it / (kavg * 1e-3)) / (peak / 2 * 1e12)
                 if kavg > 0 else 0.0,
+                # the loop's own share of the SIMDs' issue slots at the nominal clock: 6.5 VALU instructions
+                # per iteration (scaled loop, escape check every 4th), each 4 cycles per wave64 for f64
+                # (measured: tools/ubench/valu_rates.hip), 1024 SIMDs at 2.4 GHz
+                "loop_valu_issue_frac": (6.5 * launch_px_it / 64 * (4 if args.precision == "f64" else 2))
+                / (kavg * 1e-3 * 2.4e9 * 1024) if kavg > 0 else 0.0,
                 "hbm_check": {"algorithmic_bytes_per_launch": 3 * pixels // world,
                               "achieved_GBps": 3 * pixels / world / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0,
                               "peak_GBps": 8000.0},
