@@ -2,21 +2,28 @@
  * fr_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the escape-time hot path.
  *
  * Written for gfx950 only.  MUST be compiled with -ffp-contract=off and without fast-math: the
- * reference (Rust) rounds every multiply and add separately (calc/src/lib.rs:87-107), so a single
- * v_fma_f64 in the orbit loop breaks bit parity.
+ * reference (Rust) rounds every multiply and add separately (calc/src/lib.rs:87-107), so an implicit
+ * v_fma_f64 in the orbit loop breaks bit parity.  (The loops contain exactly one explicit fma, which
+ * is exact by construction — see "orbit loop, scaled form".)
  *
  * What runs where (reference lines in brackets):
- *   coordinate map   [calc/src/lib.rs:181-197]  once per block COLUMN and block ROW, by the first
- *                    lanes of the workgroup, staged in LDS — re depends only on x and im only on
- *                    y, so the 3 IEEE f64 divisions per pixel of the reference become
- *                    2 per column + 2 per row of a tile, with identical values;
- *   orbit loop       [calc/src/lib.rs:245-257, 87-107]  one wavefront lane per pixel, state in
- *                    VGPRs, exit when every lane of the wave has escaped (EXEC == 0) or the
- *                    wave-uniform counter reaches `iterations`;
- *   colour map       [calc/src/lib.rs:199-235, 133-139]  fused behind the loop; log2 is the
- *                    software fr_log2 (fr_math.h) whose 3 KB table is staged in LDS;
- *   image assembly   [src/lib.rs:253-270]  lane -> pixel mapping keeps each wave row contiguous
- *                    in the row-major output, bytes r,g,b at 3*(row*ncols + col).
+ *   coordinate map   [calc/src/lib.rs:181-197]  re depends only on x and im only on y, so a strip's
+ *                    56 column values and 8 row values are evaluated in one pass by the wave that
+ *                    renders it (the reference's 3 IEEE divisions per pixel become 2 per 7 pixels,
+ *                    same values) and handed to the pixel lanes by cross-lane reads;
+ *   orbit loop       [calc/src/lib.rs:245-257, 87-107]  one wavefront lane per pixel, state in VGPRs,
+ *                    hand-written ISA; a wave leaves it when every lane has escaped (EXEC == 0), when
+ *                    the wave-uniform counter reaches the cap, or — refilling kernel — when enough
+ *                    lanes are idle to be worth handing them new pixels;
+ *   colour map       [calc/src/lib.rs:199-235, 133-139]  fused behind the loop; log2 is the software
+ *                    fr_log2 (fr_math.h) whose 3 KB table is staged in LDS; with smooth == false the
+ *                    outside colour comes from an LDS-staged palette instead;
+ *   image assembly   [src/lib.rs:253-270]  bytes r,g,b at 3*(row*ncols + col); a wave writes 8-pixel
+ *                    (24-byte) runs of 8 rows per tile, 192-byte runs per strip row.
+ *
+ * Kernels: escape_strip_kernel (default), escape_refill_kernel (large Julia images, and the opt-in
+ * periodicity shortcut), escape_kernel (the first, 4-wave design; kept for the tile-shape study),
+ * palette_kernel, recursive_batch_kernel, math_probe_kernel (test hook).
  */
 #include "fr_kernels.h"
 
