@@ -187,8 +187,9 @@ int fr_last_kernel_ms(float *ms);
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
  * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
  * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
- * 9 = 7-tile strips with lane refill (the default for large Julia images); 6401, 3202, 1604, 808 = the 4-wave-workgroup
- * kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave pixel footprint. */
+ * 9 = 7-tile strips with lane refill (the default for large Julia images);
+ * 6401, 3202, 1604, 808 = the 4-wave-workgroup kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave
+ * pixel footprint. */
 int fr_set_tile(int tile);
 
 /* Policy of the lane-refilling kernel (tuning studies): an orbit episode may end early, so that
@@ -218,8 +219,7 @@ int fr_set_loop_mode(int mode);
 
 /* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
  * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n], 3: the `as u8` cast —
- * so tests can compare
- * the device's roundings with the host's. */
+ * so tests can compare the device's roundings with the host's. */
 int fr_debug_math(int which, const double *in, double *out, size_t n);
 
 #ifdef __cplusplus
