@@ -57,7 +57,7 @@ def _worker(rank, world, port, w, h, block_rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,w,h,block_rows", [(2, 33, 70, 8), (2, 16, 64, 8), (3, 20, 101, 16), (2, 9, 5, 8), (4, 12, 37, 4)])
+@pytest.mark.parametrize("world,w,h,block_rows", [(2, 33, 70, 8), (2, 16, 64, 8), (3, 20, 101, 16), (2, 9, 5, 8), (4, 12, 37, 4), (8, 10, 1003, 8)])
 def test_block_cyclic_gather_reassembles_the_image(world, w, h, block_rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
