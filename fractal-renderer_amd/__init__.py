@@ -26,7 +26,7 @@ from ._native import RGB, FractalHipError, Imaginary  # noqa: F401
 __all__ = [
     "Algo", "Config", "Imaginary", "RGB", "Precision", "FractalHipError",
     "get_image", "get_image_rows", "get_recursive_pixel", "recursive", "recursive_batch",
-    "escape_rows", "count_iterations", "init", "shutdown", "device_count", "device_name",
+    "escape_rows", "colour_image", "count_iterations", "init", "shutdown", "device_count", "device_name",
 ]
 
 
@@ -155,6 +155,22 @@ def escape_rows(config, y0=0, y1=None, precision=Precision.F64):
         _native.load().fr_escape_rows(C.byref(config), int(precision), y0, y1, z.ctypes.data, it.ctypes.data)
     )
     return z, it
+
+
+def colour_image(config, z, iters):
+    """The colour map alone (calc/src/lib.rs:214-234) over stored recursive() results: z float64
+    [..., 2], iters uint32 [...] -> uint8 [..., 3].  Re-colouring (exposure, colours, smooth, inside)
+    without re-iterating."""
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    iters = np.ascontiguousarray(iters, dtype=np.uint32)
+    if z.shape[:-1] != iters.shape or z.shape[-1] != 2:
+        raise ValueError("z must be [..., 2] and iters [...]")
+    out = np.empty(iters.shape + (3,), dtype=np.uint8)
+    _native.check(
+        _native.load().fr_colour_rgb8(C.byref(config), z.ctypes.data, iters.ctypes.data, iters.size, out.ctypes.data,
+                                      out.nbytes)
+    )
+    return out
 
 
 def count_iterations(config, y0=0, y1=None, sx=1, sy=1, precision=Precision.F64):

@@ -118,6 +118,9 @@ PROTOTYPES = {
         [C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_void_p, C.c_void_p],
     ),
     "fr_escape_rows": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "fr_colour_rgb8": (C.c_int, [C.POINTER(fr_config), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "fr_colour_rgb8_device": (
+        C.c_int, [C.POINTER(fr_config), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fr_count_iterations": (
         C.c_int,
         [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),

@@ -698,6 +698,43 @@ int fr_escape_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1
     return FR_OK;
 }
 
+int fr_colour_rgb8(const fr_config *cfg, const double *z_re_im, const uint32_t *iters, size_t n, uint8_t *out,
+                   size_t out_len) {
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    if (n == 0) return FR_OK;
+    if (!z_re_im || !iters || !out) return fail(FR_ERR_INVALID_ARGUMENT, "NULL array");
+    if (out_len < 3 * n) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*n");
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = ensure_locked();
+    if (rc != FR_OK) return rc;
+    rc = reserve_locked(g.z, n * 2 * sizeof(double));
+    if (rc == FR_OK) rc = reserve_locked(g.iters, n * sizeof(uint32_t));
+    if (rc == FR_OK) rc = reserve_locked(g.rgb, 3 * n);
+    if (rc != FR_OK) return rc;
+    fr_kparams p;
+    fill_params(cfg, p);
+    HIP_TRY(hipMemcpyAsync(g.z.ptr, z_re_im, n * 2 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.iters.ptr, iters, n * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(fr_launch_colour(p, static_cast<const double *>(g.z.ptr), static_cast<const uint32_t *>(g.iters.ptr), n,
+                             static_cast<uint8_t *>(g.rgb.ptr), g.stream));
+    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, 3 * n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return FR_OK;
+}
+
+int fr_colour_rgb8_device(const fr_config *cfg, const void *d_z_re_im, const void *d_iters, size_t n, void *d_out,
+                          size_t out_len, void *hip_stream) {
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    if (n == 0) return FR_OK;
+    if (!d_z_re_im || !d_iters || !d_out) return fail(FR_ERR_INVALID_ARGUMENT, "NULL array");
+    if (out_len < 3 * n) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*n");
+    fr_kparams p;
+    fill_params(cfg, p);
+    HIP_TRY(fr_launch_colour(p, static_cast<const double *>(d_z_re_im), static_cast<const uint32_t *>(d_iters), n,
+                             static_cast<uint8_t *>(d_out), static_cast<hipStream_t>(hip_stream)));
+    return FR_OK;
+}
+
 int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint32_t sx, uint32_t sy,
                         uint64_t *total, uint64_t *pixels) {
     int rc = check_rows(cfg, y0, y1);

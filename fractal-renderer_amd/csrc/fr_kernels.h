@@ -79,6 +79,11 @@ constexpr uint32_t FR_MAX_PALETTE_ENTRIES = 1280;
 /* palette[i], i = 0 .. p.iterations, for smooth == false (see fr_kparams::palette) */
 hipError_t fr_launch_palette(const fr_kparams &p, uint32_t *palette, hipStream_t stream);
 
+/* colour map only (calc/src/lib.rs:214-234) over n stored recursive() results: z (re, im
+ * interleaved) and iters -> packed r,g,b.  Device arrays. */
+hipError_t fr_launch_colour(const fr_kparams &p, const double *z, const uint32_t *iters, size_t n, uint8_t *rgb,
+                            hipStream_t stream);
+
 /* n independent orbits, device arrays (re, im interleaved) */
 hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, const double *c, size_t n,
                                      double limit, int precision, double *out_pos, uint32_t *out_iters,

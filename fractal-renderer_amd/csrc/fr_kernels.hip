@@ -1081,6 +1081,27 @@ __global__ __launch_bounds__(256) void palette_kernel(const fr_kparams p, uint32
     palette[i] = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16);
 }
 
+/* The colour map alone, over stored recursive() results — what the GUI's exposure / colour sliders
+ * need (src/gui.rs:183-203 change only inputs of calc/src/lib.rs:214-234): no orbit is re-run. */
+__global__ __launch_bounds__(256) void colour_kernel(const fr_kparams p, const double *z, const uint32_t *iters, size_t n,
+                                                   uint8_t *rgb) {
+    __shared__ double s_tab[FR_LOG2_N * 3];
+    const double *gt = &g_log2_tab[0][0];
+    for (uint32_t k = threadIdx.x; k < FR_LOG2_N * 3; k += 256) s_tab[k] = gt[k];
+    __syncthreads();
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    uint8_t out[3] = {0, 0, 0};
+    if (p.algo == 0 || p.algo == 2) {
+        const ColourConsts cc = make_colour_consts(p);
+        const double re = z[2 * k], im = z[2 * k + 1];
+        colour_of(cc, re * re + im * im, iters[k], s_tab, nullptr, out); /* pos.squared_distance(), :214 */
+    }
+    rgb[3 * k + 0] = out[0];
+    rgb[3 * k + 1] = out[1];
+    rgb[3 * k + 2] = out[2];
+}
+
 __global__ __launch_bounds__(256) void math_probe_kernel(int which, const double *in, double *out, size_t n) {
     __shared__ double s_tab[FR_LOG2_N * 3];
     const double *gt = &g_log2_tab[0][0];
@@ -1121,6 +1142,15 @@ hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, c
     else
         hipLaunchKernelGGL(recursive_batch_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, stream, iterations,
                            start, c, n, limit, out_pos, out_iters);
+    return hipGetLastError();
+}
+
+hipError_t fr_launch_colour(const fr_kparams &p, const double *z, const uint32_t *iters, size_t n, uint8_t *rgb,
+                            hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(colour_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, p, z, iters, n, rgb);
     return hipGetLastError();
 }
 

@@ -170,6 +170,16 @@ int fr_recursive_batch(uint32_t iterations, const fr_imaginary *start, const fr_
 int fr_escape_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, double *z_re_im,
                    uint32_t *iters);
 
+/* The colour map alone (calc/src/lib.rs:214-234 + color_multiply) over n stored recursive() results
+ * — e.g. the arrays fr_escape_rows returned — into packed r,g,b.  This is what the GUI's exposure,
+ * smooth/inside and colour controls need (src/gui.rs:183-203 change only inputs of the colour map):
+ * re-colouring without re-iterating.  Uses cfg's iterations, stable_limit, exposure, inside, smooth
+ * and colours; host arrays, or device arrays + stream for the _device form. */
+int fr_colour_rgb8(const fr_config *cfg, const double *z_re_im, const uint32_t *iters, size_t n, uint8_t *out,
+                   size_t out_len);
+int fr_colour_rgb8_device(const fr_config *cfg, const void *d_z_re_im, const void *d_iters, size_t n, void *d_out,
+                          size_t out_len, void *hip_stream);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 
 /* Exact sum of EXECUTED loop iterations over the pixels (x, y) with x % sx == 0, y % sy == 0 of

@@ -543,6 +543,25 @@ def test_chunked_block_cyclic_rendering_packed_and_in_place(fr, world, block_row
         assert np.array_equal(img.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("key", ["mandelbrot_default/257x193/f64", "julia_m08_0156/257x193/f32", "stable_limit_half/64x64/f64",
+                                 "huge_limit_nan_orbits/64x64/f64", "iterations_0/64x64/f64"])
+def test_recolour_without_reiterating(fr, key):
+    """fr_colour_rgb8 over stored (z, iters) reproduces get_image, and with changed colour-map inputs
+    (exposure, smooth, inside, colours, stable_limit) the image of the changed Config — the GUI's
+    sliders (src/gui.rs:183-203) never need a second orbit pass."""
+    ocfg = G.oracle_config(key)
+    prec = fr.Precision.F32 if key.endswith("f32") else fr.Precision.F64
+    op = O.F32 if key.endswith("f32") else O.F64
+    cfg = to_fr(fr, ocfg)
+    z, it = fr.escape_rows(cfg, precision=prec)
+    assert np.array_equal(fr.colour_image(cfg, z, it), G.vectors()[key + "/rgb"])
+    for change in (dict(exposure=17.5), dict(smooth=0), dict(inside=0), dict(stable_limit=0.75),
+                   dict(primary_color=(9, 200, 77), secondary_color=(255, 1, 128), exposure=0.4)):
+        ocfg2 = O.Config.from_buffer_copy(bytes(ocfg))
+        O.apply_overrides(ocfg2, change)
+        assert np.array_equal(fr.colour_image(to_fr(fr, ocfg2), z, it), oracle_image(ocfg2, op)), (key, change)
+
+
 def test_get_recursive_pixel_outside_the_image(fr):
     # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
     ocfg = O.cli_config(64, 48, iterations=80)
