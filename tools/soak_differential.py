@@ -16,13 +16,14 @@ import fractal_renderer_amd as fr  # noqa: E402
 from fractal_renderer_amd import _native  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-big = len(sys.argv) > 2 and sys.argv[2] == "big"  # large images: default dispatch reaches the 7-tile kernels
+big = len(sys.argv) > 2 and sys.argv[2] == "big"
+base = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000  # large images: default dispatch reaches the 7-tile kernels
 fr.init(0)
 lib = _native.load()
 t0 = time.time()
 bad = 0
 for seed in range(n):
-    rng = np.random.default_rng(50_000 + seed)
+    rng = np.random.default_rng(base + seed)
     ocfg = T._random_config(rng)
     if rng.random() < 0.3:  # bigger and deeper now and then
         ocfg.width, ocfg.height = int(rng.integers(300, 700)), int(rng.integers(200, 500))
