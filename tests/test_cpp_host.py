@@ -105,3 +105,33 @@ def test_cli_reproduces_reference_command_lines(tmp_path):
         finally:
             O.set_log2_mode(O.LOG2_LIBM)
         assert np.array_equal(img, want), args
+
+
+C_EXE = os.path.join(ROOT, "tests", "cpp", "test_c_abi")
+
+
+def build_c():
+    import __graft_entry__ as ge
+
+    ge.build()
+    pkg = os.path.join(ROOT, "fractal-renderer_amd")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "test_c_abi.c"), "-L" + pkg, "-lfractal_hip", "-Wl,-rpath," + pkg,
+           "-o", C_EXE]
+    subprocess.run(cmd, check=True)
+
+
+def test_header_is_plain_c_and_links():
+    build_c()
+    import fractal_renderer_amd as fr
+
+    if fr.device_count() == 0:
+        r = subprocess.run([C_EXE], capture_output=True, text=True)
+        assert r.returncode == 0 and "no device" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_abi_known_answers_from_c():
+    build_c()
+    r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "c abi ok", (r.returncode, r.stdout, r.stderr)
