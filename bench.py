@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--block-rows", type=int, default=256)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--refill", default="", help="tuning: minrun,quit16 of the refilling kernel")
+    ap.add_argument("--loop-mode", type=int, default=-1, help="tuning: force the orbit loop form (0, 2, 4)")
     ap.add_argument("--cycle-shortcut", action="store_true",
                     help="measure with the exact periodicity shortcut on (never the headline: it skips iterations)")
     ap.add_argument("--force-blocks", action="store_true",
@@ -135,6 +136,7 @@ def main():
     fr.init(local_rank)
     lib = _native.load()
     _native.check(lib.fr_set_tile(args.tile))
+    _native.check(lib.fr_set_loop_mode(args.loop_mode))
     if args.cycle_shortcut:
         _native.check(lib.fr_set_cycle_shortcut(1))
     if args.refill:
