@@ -768,3 +768,18 @@ def test_bench_smoke_small():
     assert d["roofline"]["achieved"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["gpu_bytes_identical_on_sample"] is True
     assert d["cpu_baseline"]["gpu_iteration_sum_identical_on_sample"] is True
+
+
+def test_rccl_p2p_call_pattern_self_send():
+    """The torch.distributed (RCCL) call pattern of the multi-GPU gather — P2POp batches on a side
+    stream behind an event of the compute stream — exercised on one GPU by sending to self
+    (tools/nccl_p2p_selftest.py).  A real N > 1 run is the driver's; this proves the plumbing."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_p2p_selftest.py")], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "nccl p2p self-test: ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
