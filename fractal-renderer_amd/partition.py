@@ -146,6 +146,8 @@ class DistributedRenderer:
         self.height = config.height
         self.nblocks = num_blocks(self.height, self.block_rows)
         self.cuda = render_rows is None
+        if self.cuda and self.block_rows % 8 != 0:
+            raise ValueError("block_rows must be a multiple of 8 (rank 0 renders its blocks in place, tile by tile)")
         self.force_blocks = bool(force_blocks)  # world == 1: still render block by block (tests, tuning)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.cuda else torch.device("cpu")
@@ -232,8 +234,8 @@ class DistributedRenderer:
                 continue
             # hand chunk c to the communication stream; chunk c+1 renders meanwhile
             if self.cuda:
-                if done_event is not None:
-                    self.comm_stream.wait_event(done_event)
+                if done_event is not None and r != 0:
+                    self.comm_stream.wait_event(done_event)  # a send needs its chunk; rank 0's receives do not
                 ctx = torch.cuda.stream(self.comm_stream)
             else:
                 ctx = _NullContext()
