@@ -514,10 +514,12 @@ __device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &
  * otherwise the unscaled loop.  The choice is wave-uniform. */
 template <typename T>
 __device__ __forceinline__ uint32_t orbit_auto(uint32_t loop_mode, uint32_t iterations, T &re, T &im, T cre, T cim,
-                                               T squared, T skip_t, T &r2, T &i2) {
-    if (loop_mode != 0) {
-        const bool bad = !lane_is_scalable<T>(re, im, cre, cim);
-        if (__ballot(bad) == 0ull) {
+                                               T squared, T skip_t, T &r2, T &i2, int strip_scalable = -1) {
+    if (loop_mode != 0 && strip_scalable != 0) {
+        /* admissibility: decided once per strip by the caller (1), or per call from the lanes' values */
+        bool all_ok = strip_scalable == 1;
+        if (strip_scalable < 0) all_ok = __ballot(!lane_is_scalable<T>(re, im, cre, cim)) == 0ull;
+        if (all_ok) {
             if (loop_mode == 4) return orbit_scaled<T, 4>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
             return orbit_scaled<T, 2>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
         }
@@ -537,7 +539,8 @@ __device__ __forceinline__ double coord_to_space(double coord, double max, doubl
 template <typename T, int MODE>
 __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout &out, const double *s_tab,
                                              const uint32_t *s_pal, double sre, double sim, bool valid,
-                                             uint32_t cx, uint32_t r, uint32_t lane, uint32_t r_out) {
+                                             uint32_t cx, uint32_t r, uint32_t lane, uint32_t r_out,
+                                             int strip_scalable = -1) {
     double zre = 0.0, zim = 0.0, dist = 0.0;
     uint32_t iters = 0;
     const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
@@ -549,13 +552,13 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
             zre = sre;
             zim = sim;
             iters = orbit_auto<double>(p.loop_mode, p.iterations, zre, zim, cre, cim, p.limit * p.limit, p.skip_t,
-                                       r2, i2);
+                                       r2, i2, strip_scalable);
             dist = r2 + i2; /* pos.squared_distance(), :214 */
         } else {
             float fre = (float)sre, fim = (float)sim, r2, i2;
             const float lim = (float)p.limit;
             iters = orbit_auto<float>(p.loop_mode, p.iterations, fre, fim, (float)cre, (float)cim, lim * lim,
-                                      (float)p.skip_t, r2, i2);
+                                      (float)p.skip_t, r2, i2, strip_scalable);
             zre = (double)fre;
             zim = (double)fim;
             dist = zre * zre + zim * zim;
@@ -631,6 +634,29 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
     render_pixel<T, MODE>(p, out, s_tab, nullptr, s_re[lx], s_im[ly], valid, cx, r, lane, r);
 }
 
+/* May a whole strip run the scaled loop (see "orbit loop, scaled form")?  Every c and start
+ * component must be admissible; for a strip they are its 56 column and 8 row coordinates (Mandelbrot:
+ * c = start; Julia: c = julia_set, start = the coordinates), held one per lane in `coord_lane`.
+ * Columns / rows past the image edge never become pixels and are ignored. */
+template <typename T>
+__device__ __forceinline__ bool strip_is_scalable(const fr_kparams &p, double coord_lane, uint32_t tile0, uint32_t row0,
+                                                  uint32_t lane) {
+    constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
+    const bool row_lane = lane >= 56;
+    const T v = (T)coord_lane;
+    const T av = __builtin_fabs(v);
+    const bool in_range = av >= lo && av <= hi;
+    bool lane_ok;
+    if (p.algo == 2) {
+        const T jr = __builtin_fabs((T)p.julia_re), ji = __builtin_fabs((T)p.julia_im);
+        lane_ok = (v == (T)0 || in_range) && jr >= lo && jr <= hi && ji >= lo && ji <= hi;
+    } else {
+        lane_ok = in_range;
+    }
+    const bool relevant = row_lane ? (row0 + (lane - 56) < p.nrows) : (tile0 * 8u + lane < p.ncols);
+    return __ballot(relevant && !lane_ok) == 0ull;
+}
+
 /* Default kernel: ONE WAVE PER WORKGROUP renders a horizontal strip of kStripTiles 8x8 tiles
  * (64 x 8 pixels at 8 tiles), one tile at a time.
  *
@@ -693,6 +719,7 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
     uint32_t out_row0 = row0;
     if (p.out_in_place) out_row0 = p.y_first + (row0 / p.block_rows) * p.y_stride + row0 % p.block_rows;
     const uint32_t r_out = out_row0 + ly;
+    const int strip_scalable = (p.loop_mode != 0 && strip_is_scalable<T>(p, coord_lane, tile0, row0, lane)) ? 1 : 0;
 
     for (int k = 0; k < kStripTiles; k++) {
         const uint32_t col0 = (tile0 + k) * 8u;
@@ -700,7 +727,7 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
         const double sre = __shfl(coord_lane, k * 8 + lx, 64);
         const uint32_t cx = col0 + lx;
         const bool valid = cx < p.ncols && r < p.nrows;
-        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane, r_out);
+        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane, r_out, strip_scalable);
     }
 }
 
@@ -906,26 +933,8 @@ __global__ __launch_bounds__(64) void escape_refill_kernel(const fr_kparams p, c
     const double coord_lane = coord_to_space((double)coord_u, height, row_lane ? 0.5 : (width / height) / 2.0,
                                              row_lane ? p.pos_im : p.pos_re, row_lane ? p.scale_im : p.scale_re);
 
-    /* May the whole strip run the scaled loop (fr_kernels.hip, "orbit loop, scaled form")?  Every c
-     * and start component must be admissible; for this strip they are the 56 column and 8 row
-     * coordinates (Mandelbrot: c = start; Julia: c = julia_set, start = the coordinates). */
     bool scaled_ok = false;
-    if constexpr (FORM != 0) {
-        constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
-        const T v = (T)coord_lane;
-        const T av = __builtin_fabs(v);
-        const bool in_range = av >= lo && av <= hi;
-        bool lane_ok;
-        if (p.algo == 2) {
-            const T jr = __builtin_fabs((T)p.julia_re), ji = __builtin_fabs((T)p.julia_im);
-            lane_ok = (v == (T)0 || in_range) && jr >= lo && jr <= hi && ji >= lo && ji <= hi;
-        } else {
-            lane_ok = in_range;
-        }
-        /* columns past the image edge never become pixels; ignore what their lanes computed */
-        const bool relevant = row_lane ? (row0 + (lane - 56) < p.nrows) : (tile0 * 8u + lane < p.ncols);
-        scaled_ok = __ballot(relevant && !lane_ok) == 0ull;
-    }
+    if constexpr (FORM != 0) scaled_ok = strip_is_scalable<T>(p, coord_lane, tile0, row0, lane);
     if (FORM != 0 && scaled_ok)
         refill_strip<T, MODE, kStripTiles, FORM, CYC>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
     else
