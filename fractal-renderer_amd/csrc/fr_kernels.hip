@@ -635,15 +635,14 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
 }
 
 /* May a whole strip run the scaled loop (see "orbit loop, scaled form")?  Every c and start
- * component must be admissible; for a strip they are its 56 column and 8 row coordinates (Mandelbrot:
- * c = start; Julia: c = julia_set, start = the coordinates), held one per lane in `coord_lane`.
- * Columns / rows past the image edge never become pixels and are ignored. */
+ * component must be admissible; for a strip they are its column and row coordinates (Mandelbrot:
+ * c = start; Julia: c = julia_set, start = the coordinates).  coords_admissible() tests one
+ * coordinate per lane (`relevant` masks lanes whose column / row lies past the image edge and never
+ * becomes a pixel) and returns the wave-uniform verdict. */
 template <typename T>
-__device__ __forceinline__ bool strip_is_scalable(const fr_kparams &p, double coord_lane, uint32_t tile0, uint32_t row0,
-                                                  uint32_t lane) {
+__device__ __forceinline__ bool coords_admissible(const fr_kparams &p, double coord, bool relevant) {
     constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
-    const bool row_lane = lane >= 56;
-    const T v = (T)coord_lane;
+    const T v = (T)coord;
     const T av = __builtin_fabs(v);
     const bool in_range = av >= lo && av <= hi;
     bool lane_ok;
@@ -653,8 +652,15 @@ __device__ __forceinline__ bool strip_is_scalable(const fr_kparams &p, double co
     } else {
         lane_ok = in_range;
     }
-    const bool relevant = row_lane ? (row0 + (lane - 56) < p.nrows) : (tile0 * 8u + lane < p.ncols);
     return __ballot(relevant && !lane_ok) == 0ull;
+}
+
+/* the strip kernel's layout: columns on lanes 0-55, the 8 rows on lanes 56-63 of one register */
+template <typename T>
+__device__ __forceinline__ bool strip_is_scalable(const fr_kparams &p, double coord_lane, uint32_t tile0, uint32_t row0,
+                                                  uint32_t lane) {
+    const bool relevant = lane >= 56 ? (row0 + (lane - 56) < p.nrows) : (tile0 * 8u + lane < p.ncols);
+    return coords_admissible<T>(p, coord_lane, relevant);
 }
 
 /* Default kernel: ONE WAVE PER WORKGROUP renders a horizontal strip of kStripTiles 8x8 tiles
@@ -733,9 +739,9 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
 
 /* ---- strip kernel with lane refill ------------------------------------------------------------
  *
- * Same strip decomposition, but a lane whose pixel has finished (escaped, or reached the cap) is
- * handed the next unstarted pixel of the strip instead of idling until the slowest lane of its 8x8
- * tile is done.  Views without a large interior (Julia sets, zoomed exteriors) leave two thirds of
+ * One wave renders a patch of 7 x 2 tiles (56 x 16 pixels), and a lane whose pixel has finished
+ * (escaped, or reached the cap) is handed the next unstarted pixel of the patch instead of idling
+ * until the slowest lane of its 8x8 tile is done.  Views without a large interior (Julia sets, zoomed exteriors) leave two thirds of
  * the lanes idle with one tile per wave (measured useful-lane fraction of C4: 0.35).
  *
  * The orbit loops run as EPISODES (orbit_run / orbit_scaled_run): an episode ends when every
@@ -768,14 +774,21 @@ __device__ __forceinline__ T cycle_none() { /* a state no orbit passes through: 
         return __builtin_bit_cast(float, 0x7FC00001u);
 }
 
+/* The refilling kernel's pool of pixels is a PATCH of kStripTiles x kRefillBands tiles: the larger
+ * the pool a wave draws from, the fewer lanes idle while the last long orbits of the pool finish
+ * (simulated useful-lane fraction on C4: 0.58 with one 7-tile strip, 0.67 with 2 bands, 0.74 with 8) —
+ * but the fewer, longer-lived waves there are to balance over the chip.  Measured on C4 (f32):
+ * 1 band 3.65 ms, 2 bands 3.48, 4 bands 3.53, 8 bands 3.97; 2 it is (56 x 16 pixels).  Column coordinates live one per lane in `cols` (lanes 0-55), row coordinates in `rows`
+ * (lanes 0-63), the rows' output positions in `out_rows`; pixel ids run tile-major:
+ * pid = ((band * kStripTiles + tile) * 64) + ly * 8 + lx. */
+constexpr int kRefillBands = 2;
+
 template <typename T, int MODE, int kStripTiles, int FORM, bool CYC>
-__device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout &out, const double *s_tab,
-                                             const uint32_t *s_pal, double coord_lane, uint32_t tile0, uint32_t row0,
-                                             uint32_t lane) {
+__device__ __forceinline__ void refill_patch(const fr_kparams &p, const fr_kout &out, const double *s_tab,
+                                             const uint32_t *s_pal, double cols, double rows, uint32_t out_rows,
+                                             uint32_t tile0, uint32_t row0, uint32_t lane) {
     static_assert(!(CYC && FORM == 0), "the periodicity check lives in the scaled loops");
-    uint32_t out_row0 = row0; /* packed, or the strip's image row (in place); see escape_strip_kernel */
-    if (p.out_in_place) out_row0 = p.y_first + (row0 / p.block_rows) * p.y_stride + row0 % p.block_rows;
-    constexpr uint32_t P = kStripTiles * 64;
+    constexpr uint32_t P = kStripTiles * kRefillBands * 64;
     const ColourConsts cc = make_colour_consts(p);
     const bool julia = p.algo == 2;
     const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
@@ -785,22 +798,25 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
     T a0 = 0, a1 = 0, a2 = 0, a3 = 0; /* FORM 0: re, im, re*re, im*im;  scaled: X, Y, A, B */
     T c0 = 0, c1 = 0;                 /* FORM 0: c.re, c.im;            scaled: 2c.re, 2c.im */
     T xs = cycle_none<T>(), ys = cycle_none<T>(); /* CYC: this orbit's state after `saved_at` iterations */
-    uint32_t pid = 0, done = 0, next = 0, saved_at = 0;
+    uint32_t done = 0, next = 0, saved_at = 0;
+    uint32_t px = 0, py = 0, pout = 0; /* the lane's pixel: local column, local row, output row */
     bool busy = false;
     unsigned long long count_acc = 0;
 
     while (true) {
-        /* ---- hand unstarted pixels to the free lanes (tile-major order: pid = tile*64 + ly*8 + lx) */
+        /* ---- hand unstarted pixels to the free lanes */
         const unsigned long long free_mask = __ballot(!busy);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32),
                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
-        const uint32_t cand = busy ? 0u : next + rank;
-        const uint32_t ck = (cand >> 6) < (uint32_t)kStripTiles ? (cand >> 6) : 0u;
+        const uint32_t cand = (busy || next + rank >= P) ? 0u : next + rank;
+        const uint32_t ct = cand >> 6, cband = ct / (uint32_t)kStripTiles, ctile = ct - cband * (uint32_t)kStripTiles;
+        const uint32_t ccol = ctile * 8u + (cand & 7u), crow = cband * 8u + ((cand >> 3) & 7u);
         /* cross-lane reads by ALL lanes (a masked-off source lane would not deliver its value) */
-        const double sre = __shfl(coord_lane, ck * 8 + (cand & 7u), 64);
-        const double sim = __shfl(coord_lane, 56 + ((cand >> 3) & 7u), 64);
-        if (!busy && cand < P) {
-            const uint32_t cx = (tile0 + (cand >> 6)) * 8u + (cand & 7u), r = row0 + ((cand >> 3) & 7u);
+        const double sre = __shfl(cols, ccol, 64);
+        const double sim = __shfl(rows, crow, 64);
+        const uint32_t sout = __shfl(out_rows, crow, 64);
+        if (!busy && next + rank < P) {
+            const uint32_t cx = tile0 * 8u + ccol, r = row0 + crow;
             if (cx < p.ncols && r < p.nrows) {
                 const T zre = (T)sre, zim = (T)sim;
                 const T cre = julia ? (T)p.julia_re : zre, cim = julia ? (T)p.julia_im : zim; /* :209-210 */
@@ -810,7 +826,7 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                     a0 = zre + zre, a1 = zim + zim, a2 = a0 * a0, a3 = a1 * a1, c0 = cre + cre, c1 = cim + cim;
                 }
                 if constexpr (CYC) xs = ys = cycle_none<T>(), saved_at = 0; /* the previous pixel's save is not ours */
-                pid = cand;
+                px = cx, py = r, pout = sout;
                 done = 0;
                 busy = true;
             }
@@ -823,8 +839,7 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
             continue; /* only out-of-image pixels were handed out; take the next ones */
         }
 
-        /* ---- one episode */
-        /* run until the lane closest to its cap gets there */
+        /* ---- one episode: run until the lane closest to its cap gets there (or the policy quits) */
         const uint32_t n = wave_min_u32(busy ? iterations - done : 0xFFFFFFFFu);
         const uint32_t nbusy = (uint32_t)__builtin_popcountll(busy_mask);
         EpisodeCtl ctl{0u, 0u};
@@ -871,17 +886,15 @@ __device__ __forceinline__ void refill_strip(const fr_kparams &p, const fr_kout 
                 }
                 const double zre = (double)fre, zim = (double)fim;
                 const double dist = sizeof(T) == 8 ? (double)(fr2 + fi2) : zre * zre + zim * zim; /* :214 */
-                const uint32_t cx = (tile0 + (pid >> 6)) * 8u + (pid & 7u), r = row0 + ((pid >> 3) & 7u);
                 if constexpr (MODE == FR_OUT_RGB) {
                     uint8_t rgb[3];
                     colour_of(cc, dist, iters, s_tab, s_pal, rgb);
-                    const uint32_t r_out = out_row0 + ((pid >> 3) & 7u);
-                    uint8_t *o = out.rgb + 3ull * ((uint64_t)r_out * p.ncols + cx);
+                    uint8_t *o = out.rgb + 3ull * ((uint64_t)pout * p.ncols + px);
                     o[0] = rgb[0];
                     o[1] = rgb[1];
                     o[2] = rgb[2];
                 } else if constexpr (MODE == FR_OUT_ESCAPE) {
-                    const uint64_t kk = (uint64_t)r * p.ncols + cx;
+                    const uint64_t kk = (uint64_t)py * p.ncols + px;
                     if (out.z) {
                         out.z[2 * kk] = zre;
                         out.z[2 * kk + 1] = zim;
@@ -917,28 +930,28 @@ __global__ __launch_bounds__(64) void escape_refill_kernel(const fr_kparams p, c
         }
         __syncthreads();
     }
-    const uint32_t row0 = (blockIdx.y + gridDim.y * blockIdx.z) * 8u;
+    static_assert(kStripTiles <= 7 && kRefillBands <= 8, "column lanes 0-55, row lanes 0-63");
+    const uint32_t row0 = (blockIdx.y + gridDim.y * blockIdx.z) * (8u * kRefillBands);
     if (row0 >= p.nrows) return;
     const uint32_t tile0 = blockIdx.x * kStripTiles;
-    static_assert(kStripTiles <= 7, "lanes 56-63 are the row lanes");
     const double width = (double)p.width, height = (double)p.height;
-    const bool row_lane = lane >= 56;
-    uint32_t coord_u;
-    if (row_lane) {
-        const uint32_t rr = row0 + (lane - 56);
-        coord_u = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
-    } else {
-        coord_u = p.x_first + (tile0 * 8u + lane) * p.x_stride;
-    }
-    const double coord_lane = coord_to_space((double)coord_u, height, row_lane ? 0.5 : (width / height) / 2.0,
-                                             row_lane ? p.pos_im : p.pos_re, row_lane ? p.scale_im : p.scale_re);
+    /* the patch's coordinate map (calc/src/lib.rs:182-197), one column and one row per lane */
+    const uint32_t x = p.x_first + (tile0 * 8u + lane) * p.x_stride;
+    const double cols = coord_to_space((double)x, height, (width / height) / 2.0, p.pos_re, p.scale_re);
+    const uint32_t rr = row0 + lane;
+    const uint32_t y = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
+    const double rows = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
+    /* where local row rr goes: packed, or its image row (in place) */
+    const uint32_t out_rows = p.out_in_place ? y : rr;
 
     bool scaled_ok = false;
-    if constexpr (FORM != 0) scaled_ok = strip_is_scalable<T>(p, coord_lane, tile0, row0, lane);
+    if constexpr (FORM != 0)
+        scaled_ok = coords_admissible<T>(p, cols, lane < 8u * kStripTiles && tile0 * 8u + lane < p.ncols) &&
+                    coords_admissible<T>(p, rows, rr < p.nrows);
     if (FORM != 0 && scaled_ok)
-        refill_strip<T, MODE, kStripTiles, FORM, CYC>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
+        refill_patch<T, MODE, kStripTiles, FORM, CYC>(p, out, s_tab, s_pal, cols, rows, out_rows, tile0, row0, lane);
     else
-        refill_strip<T, MODE, kStripTiles, 0, false>(p, out, s_tab, s_pal, coord_lane, tile0, row0, lane);
+        refill_patch<T, MODE, kStripTiles, 0, false>(p, out, s_tab, s_pal, cols, rows, out_rows, tile0, row0, lane);
 }
 
 template <typename T, int kStripTiles, int FORM, bool CYC>
@@ -962,9 +975,9 @@ template <typename T, int kStripTiles>
 hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipStream_t stream) {
     if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
     const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
-    const uint64_t row_tiles = ((uint64_t)p.nrows + 7) / 8;
-    const uint64_t gy = row_tiles < 32768 ? row_tiles : 32768;
-    const uint64_t gz = (row_tiles + gy - 1) / gy;
+    const uint64_t row_patches = ((uint64_t)p.nrows + 8 * kRefillBands - 1) / (8 * kRefillBands);
+    const uint64_t gy = row_patches < 32768 ? row_patches : 32768;
+    const uint64_t gz = (row_patches + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
     if (p.loop_mode == 4 && p.cycle_shortcut) return launch_refill_form<T, kStripTiles, 4, true>(p, mode, out, grid, stream);
