@@ -562,6 +562,44 @@ def test_recolour_without_reiterating(fr, key):
         assert np.array_equal(fr.colour_image(to_fr(fr, ocfg2), z, it), oracle_image(ocfg2, op)), (key, change)
 
 
+DEGENERATE = {
+    "limit_nan": dict(limit=float("nan")), "limit_inf": dict(limit=float("inf")), "limit_negative": dict(limit=-3.0),
+    "limit_zero": dict(limit=0.0), "limit_1e300": dict(limit=1e300),
+    "stable_nan": dict(stable_limit=float("nan")), "stable_inf": dict(stable_limit=float("inf")),
+    "stable_negative": dict(stable_limit=-1.0),
+    "exposure_nan": dict(exposure=float("nan")), "exposure_inf": dict(exposure=float("inf")), "exposure_zero": dict(exposure=0.0),
+    "scale_zero": dict(scale=(0.0, 0.4)), "scale_negative": dict(scale=(-0.4, -0.4)), "scale_nan": dict(scale=(float("nan"), 0.4)),
+    "scale_inf": dict(scale=(float("inf"), float("inf"))), "scale_tiny": dict(scale=(1e-300, 1e-300)),
+    "pos_inf": dict(pos=(float("inf"), 0.0)), "pos_nan": dict(pos=(0.0, float("nan"))), "pos_huge": dict(pos=(1e200, -1e200)),
+    "julia_nan": dict(algo=O.JULIA, julia_set=(float("nan"), 0.1)), "julia_inf": dict(algo=O.JULIA, julia_set=(float("inf"), 0.0)),
+    "julia_huge": dict(algo=O.JULIA, julia_set=(1e300, -1e300)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DEGENERATE))
+def test_nonfinite_and_degenerate_parameters(fr, name):
+    """NaN / infinite / zero / negative parameters: whatever the reference's arithmetic does with them
+    (NaN never compares greater, `as u8` maps NaN to 0, ...) the device must do too, in every loop form."""
+    from fractal_renderer_amd import _native
+
+    kw = dict(DEGENERATE[name])
+    algo = kw.pop("algo", O.MANDELBROT)
+    ocfg = O.cli_config(72, 40, algo, iterations=30, **kw)
+    cfg = to_fr(fr, ocfg)
+    lib = _native.load()
+    try:
+        for mode in (-1, 0, 4):
+            lib.fr_set_loop_mode(mode)
+            for op, fp in ((O.F64, fr.Precision.F64), (O.F32, fr.Precision.F32)):
+                z, it = fr.escape_rows(cfg, precision=fp)
+                wz, wit = O.escape_rows(ocfg, op)
+                assert np.array_equal(it, wit), (name, mode, op)
+                assert same_f64(z, wz), (name, mode, op)
+                assert np.array_equal(fr.get_image(cfg, fp), oracle_image(ocfg, op)), (name, mode, op)
+    finally:
+        lib.fr_set_loop_mode(-1)
+
+
 def test_get_recursive_pixel_outside_the_image(fr):
     # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
     ocfg = O.cli_config(64, 48, iterations=80)
