@@ -25,7 +25,7 @@ from ._native import RGB, FractalHipError, Imaginary  # noqa: F401
 
 __all__ = [
     "Algo", "Config", "Imaginary", "RGB", "Precision", "FractalHipError",
-    "get_image", "get_image_rows", "get_recursive_pixel", "recursive", "recursive_batch",
+    "get_image", "get_image_rows", "get_image_rgba", "get_recursive_pixel", "recursive", "recursive_batch",
     "escape_rows", "colour_image", "count_iterations", "init", "shutdown", "device_count", "device_name",
 ]
 
@@ -111,6 +111,17 @@ def get_image(config, precision=Precision.F64):
         _native.check(_native.load().fr_render_rgb8(C.byref(config), out.ctypes.data, out.nbytes))
         return out
     return get_image_rows(config, 0, config.height, precision, out)
+
+
+def get_image_rgba(config, precision=Precision.F64):
+    """get_image as RGBA8 (alpha 255): uint8 [height, width, 4] — the GUI's upload format
+    (src/gui.rs:71-72) produced on the device."""
+    out = np.empty((config.height, config.width, 4), dtype=np.uint8)
+    _native.check(
+        _native.load().fr_render_rows_rgba8(C.byref(config), int(precision), 0, config.height, out.ctypes.data,
+                                            out.nbytes)
+    )
+    return out
 
 
 def get_recursive_pixel(config, x, y, precision=Precision.F64):

@@ -91,6 +91,11 @@ PROTOTYPES = {
         C.c_int,
         [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "fr_render_rows_rgba8": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "fr_render_rows_rgba8_device": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "fr_render_block_cyclic_rgb8_device": (
         C.c_int,
         [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,

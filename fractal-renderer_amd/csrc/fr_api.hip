@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -436,22 +437,55 @@ void fr_config_new(fr_config *cfg, uint32_t algo) {
     cfg->color_weight = 0.01;
 }
 
-int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
-                               size_t out_len, void *hip_stream) {
+static int render_rows_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                              size_t out_len, void *hip_stream, unsigned bytes_per_pixel) {
     int rc = check_rows(cfg, y0, y1);
     if (rc == FR_OK) rc = check_precision(precision);
     if (rc != FR_OK) return rc;
-    const size_t need = (size_t)3 * cfg->width * (size_t)(y1 - y0);
+    const size_t need = (size_t)bytes_per_pixel * cfg->width * (size_t)(y1 - y0);
     if (need == 0) return FR_OK;
     if (!d_out) return fail(FR_ERR_INVALID_ARGUMENT, "d_out is NULL");
-    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*(y1-y0)");
+    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < bytes_per_pixel*width*(y1-y0)");
+    if (bytes_per_pixel == 4 && (reinterpret_cast<uintptr_t>(d_out) & 3u))
+        return fail(FR_ERR_INVALID_ARGUMENT, "RGBA8 output must be 4-byte aligned");
     fr_kparams p;
     fill_params(cfg, p);
     p.nrows = y1 - y0;
     p.y_first = y0;
     p.block_rows = p.nrows;
     p.y_stride = 0;
+    p.out_rgba = bytes_per_pixel == 4 ? 1u : 0u;
     return render_device(cfg, p, precision, d_out, static_cast<hipStream_t>(hip_stream));
+}
+
+int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                               size_t out_len, void *hip_stream) {
+    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 3);
+}
+
+int fr_render_rows_rgba8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                                size_t out_len, void *hip_stream) {
+    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 4);
+}
+
+int fr_render_rows_rgba8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out, size_t out_len) {
+    int rc = check_rows(cfg, y0, y1);
+    if (rc == FR_OK) rc = check_precision(precision);
+    if (rc != FR_OK) return rc;
+    const size_t need = (size_t)4 * cfg->width * (size_t)(y1 - y0);
+    if (need == 0) return FR_OK;
+    if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
+    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 4*width*(y1-y0)");
+    std::lock_guard<std::mutex> lk(g.mu);
+    rc = ensure_locked();
+    if (rc != FR_OK) return rc;
+    rc = reserve_locked(g.rgb, need);
+    if (rc != FR_OK) return rc;
+    rc = fr_render_rows_rgba8_device(cfg, precision, y0, y1, g.rgb.ptr, need, g.stream);
+    if (rc != FR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, need, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return FR_OK;
 }
 
 uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t first_block, uint32_t block_stride) {

@@ -35,6 +35,9 @@ struct fr_kparams {
      * IMAGE row y: the destination is the whole image).  In place needs block_rows % 8 == 0 so that
      * an 8-row tile never straddles two blocks. */
     uint32_t out_in_place;
+    /* RGB output pixel format: 0 = packed r,g,b (the reference's Vec<RGB>), 1 = r,g,b,255 (RGBA8, what
+     * the GUI converts the image to before uploading it, src/gui.rs:71-72) */
+    uint32_t out_rgba;
     /* orbit-loop plan chosen by the host (fr_api.hip: plan_loop): 0 = unscaled loop, escape
      * check every iteration; 4 / 2 = scaled loop, escape check every 4th / 2nd iteration while
      * every live lane of the wave has |z|^2 <= skip_t (see fr_kernels.hip). */

@@ -533,6 +533,21 @@ __device__ __forceinline__ double coord_to_space(double coord, double max, doubl
     return ((coord / max) - offset) / scale + pos;
 }
 
+/* store one finished pixel: packed r,g,b at 3*(row*ncols + col), or one r,g,b,255 dword at 4*(...) */
+__device__ __forceinline__ void store_pixel(const fr_kparams &p, uint8_t *base, uint32_t row, uint32_t col,
+                                            const uint8_t rgb[3]) {
+    const uint64_t k = (uint64_t)row * p.ncols + col;
+    if (p.out_rgba) {
+        reinterpret_cast<uint32_t *>(base)[k] =
+            (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16) | 0xFF000000u;
+    } else {
+        uint8_t *o = base + 3ull * k;
+        o[0] = rgb[0];
+        o[1] = rgb[1];
+        o[2] = rgb[2];
+    }
+}
+
 /* One pixel per lane, from its start coordinate to its output: orbit loop, then the colour map
  * (MODE RGB), the raw recursive() result (MODE ESCAPE) or the executed-iteration sum (MODE COUNT).
  * Every lane of the wave calls this together; `valid` masks lanes that fall outside the image. */
@@ -572,10 +587,7 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
                 const ColourConsts cc = make_colour_consts(p);
                 colour_of(cc, dist, iters, s_tab, s_pal, rgb);
             }
-            uint8_t *o = out.rgb + 3ull * ((uint64_t)r_out * p.ncols + cx);
-            o[0] = rgb[0];
-            o[1] = rgb[1];
-            o[2] = rgb[2];
+            store_pixel(p, out.rgb, r_out, cx, rgb);
         }
     } else if constexpr (MODE == FR_OUT_ESCAPE) {
         if (valid) {
@@ -889,10 +901,7 @@ __device__ __forceinline__ void refill_patch(const fr_kparams &p, const fr_kout 
                 if constexpr (MODE == FR_OUT_RGB) {
                     uint8_t rgb[3];
                     colour_of(cc, dist, iters, s_tab, s_pal, rgb);
-                    uint8_t *o = out.rgb + 3ull * ((uint64_t)pout * p.ncols + px);
-                    o[0] = rgb[0];
-                    o[1] = rgb[1];
-                    o[2] = rgb[2];
+                    store_pixel(p, out.rgb, pout, px, rgb);
                 } else if constexpr (MODE == FR_OUT_ESCAPE) {
                     const uint64_t kk = (uint64_t)py * p.ncols + px;
                     if (out.z) {

@@ -129,6 +129,13 @@ int fr_render_rows_rgb8(const fr_config *cfg, int precision, uint32_t y0, uint32
 int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1,
                                void *d_out, size_t out_len, void *hip_stream);
 
+/* The same rows as RGBA8 (bytes r,g,b,255; 4*width*(y1-y0) bytes; device pointer 4-byte aligned): what
+ * the reference's GUI converts the Vec<RGB> to on the CPU before uploading it (src/gui.rs:71-72). */
+int fr_render_rows_rgba8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out,
+                         size_t out_len);
+int fr_render_rows_rgba8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                                size_t out_len, void *hip_stream);
+
 /* Row-block-cyclic share of the image for multi-GPU rendering: blocks of `block_rows` rows,
  * this call renders blocks first_block, first_block + block_stride, ... and packs them
  * contiguously into d_out (device memory).  *rows_written (may be NULL) receives the number of

@@ -600,6 +600,23 @@ def test_nonfinite_and_degenerate_parameters(fr, name):
         lib.fr_set_loop_mode(-1)
 
 
+@pytest.mark.parametrize("key", ["mandelbrot_default/257x193/f64", "julia_m08_0156/257x193/f32", "unsmooth/257x193/f64"])
+@pytest.mark.parametrize("tile", [0, 9, 808])
+def test_rgba8_output(fr, key, tile):
+    """RGBA8 variant (the GUI's upload format, src/gui.rs:71-72): same r,g,b as get_image, alpha 255."""
+    from fractal_renderer_amd import _native
+
+    cfg = to_fr(fr, G.oracle_config(key))
+    prec = fr.Precision.F32 if key.endswith("f32") else fr.Precision.F64
+    try:
+        _native.check(_native.load().fr_set_tile(tile))
+        rgba = fr.get_image_rgba(cfg, prec)
+    finally:
+        _native.load().fr_set_tile(0)
+    assert np.array_equal(rgba[..., :3], G.vectors()[key + "/rgb"])
+    assert (rgba[..., 3] == 255).all()
+
+
 def test_get_recursive_pixel_outside_the_image(fr):
     # get_recursive_pixel does not clamp x, y to width/height (calc/src/lib.rs:199-207)
     ocfg = O.cli_config(64, 48, iterations=80)
