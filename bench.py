@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
+"""bench.py — BASELINE.json's metric on BASELINE.json's configs, on N MI355X of one node.
 
 Metric: pixel-iterations/s: Σ over pixels of EXECUTED loop iterations ÷ time, the
 Σ being an exact integer counted on the device outside the timed region (and cross-checked against
-the CPU oracle on the sampled pixels of the cpu_baseline leg).
+the CPU oracle by the cpu_baseline leg).
 
-Workload at N GPUs (weak scaling, per-GPU pixel count fixed at 16384² = BASELINE config C2):
-    Mandelbrot, default view (-x -0.6 -y 0 -s 0.4), max_iter 1024, fp64, image W = H = round(16384·√N)
-    (N=1: 16384², N=4: 32768², N=2/8: 23170² / 46341²), row-block-cyclic over the ranks.
-A step = one pass of the hot path over the whole image: every rank renders its row blocks into
-HBM (inputs are just the Config; outputs stay resident in HBM), and for N > 1 every finished block
-is sent to rank 0 over RCCL point-to-point, straight into its place in the full image, while the
-next block renders (the path's one real exchange step, north_star: "final RCCL gather over xGMI").
+Workloads (--workload):
+    c2    (default) Mandelbrot 16384², default view (-x -0.6 -y 0 -s 0.4), max_iter 1024, fp64 — the
+          config BASELINE.json's metric is quoted on.  At N GPUs the SAME image is split
+          row-block-cyclically over the ranks ("scaling": "strong": the metric reads "at 16384², 1/2/4/8 GPU").
+    c5    Mandelbrot 65536², same view and cap (BASELINE C5: "65536² tiled across 8 GPUs"), any N.
+    weak  per-GPU pixel count fixed at 16384²: W = H = round(16384·√N).
+A step = one pass of the hot path over the whole image: every rank renders its row blocks into HBM
+(inputs are just the Config; outputs stay resident in HBM) and, for N > 1, every finished block travels
+to the first GPU over xGMI — straight into its place in the full image — while the next ones render
+(the path's one real exchange step, north_star: "final RCCL gather over xGMI").
+
+How N > 1 runs:
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, what the
+    driver does): one process per GPU, the gather is torch.distributed point-to-point = RCCL;
+  * plain `python3 bench.py --gpus N`: ONE process drives all N GPUs through the library's own
+    multi-device entry points (fr_init_devices + fr_render_rgb8_multi_device: one host thread and one
+    set of streams per GPU, gather by grouped ncclSend/ncclRecv; --gather peer for xGMI peer DMA), and
+    also times the host-buffer variant (every GPU DMAs its blocks to the caller's buffer over its own
+    PCIe link).  On a box with fewer than N GPUs it prints a JSON line with an "error" field and exits 0.
 
 One JSON line on stdout (rank 0).  `roofline` prices the escape+colour kernel against the gfx950
-fp64 VECTOR peak (this path is neither HBM- nor MFMA-bound); `cpu_baseline` is the
-oracle's row-parallel driver timed on this box's host cores on a bounded sample.
+VECTOR peak of the arithmetic type (this path is neither HBM- nor MFMA-bound);
+`cpu_baseline` is the oracle's row-parallel driver timed on this box's host cores.
 """
 import argparse
 import ctypes as C
@@ -32,7 +44,13 @@ sys.path.insert(0, ROOT)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop(FMA) x 2.4 GHz
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 FLOPS_PER_ITERATION = 10  # as written in the reference: calc/src/lib.rs:88-89,95,103-104
-VALU_OPS_PER_ITERATION = 8  # after reusing re², im² (bit-safe); FMA is forbidden by bit-exactness
+
+VIEWS = {
+    # name: (algo, pos, scale, julia_set)
+    "default": ("mandelbrot", (-0.6, 0.0), 0.4, None),
+    "zoom1e6": ("mandelbrot", (-0.7436447860, 0.1318252536), 1e6, None),
+    "julia": ("julia", (0.0, 0.0), 0.4, (-0.8, 0.156)),
+}
 
 
 def parse_args():
@@ -40,74 +58,513 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=16384, help="per-GPU image edge (default: BASELINE C2)")
+    ap.add_argument("--workload", choices=["c2", "c5", "weak"], default="c2")
+    ap.add_argument("--size", type=int, default=0, help="image edge (overrides the workload's)")
     ap.add_argument("--iterations", type=int, default=1024)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--view", choices=["default", "zoom1e6", "julia"], default="default")
+    ap.add_argument("--view", choices=sorted(VIEWS), default="default")
     ap.add_argument("--block-rows", type=int, default=256)
+    ap.add_argument("--gather", choices=["rccl", "peer"], default="rccl",
+                    help="single-process N > 1: how finished blocks reach the first GPU")
+    ap.add_argument("--logical", action="store_true",
+                    help="single-process N > 1 on fewer GPUs: N logical devices on GPU 0 (a plumbing check, "
+                         "never a scaling number)")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--refill", default="", help="tuning: minrun,quit16 of the refilling kernel")
     ap.add_argument("--loop-mode", type=int, default=-1, help="tuning: force the orbit loop form (0, 2, 4)")
+    ap.add_argument("--no-colour-filter", action="store_true", help="tuning: always the f64 software log2")
     ap.add_argument("--cycle-shortcut", action="store_true",
                     help="measure with the exact periodicity shortcut on (never the headline: it skips iterations)")
     ap.add_argument("--force-blocks", action="store_true",
                     help="N=1 only: render block by block like a rank of an N>1 run does (tuning of --block-rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores available)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every core this process may use")
     return ap.parse_args()
 
 
-def make_config(fr, args, edge):
+def make_config(fr, view, edge, iterations):
     """CLI-default Config (src/lib.rs:34-226: limit 65536, stable_limit 2, exposure 5, inside,
     smooth, default colours) for the chosen view."""
-    cfg = fr.Config.new(fr.Algo.Julia if args.view == "julia" else fr.Algo.Mandelbrot)
+    algo, pos, scale, julia = VIEWS[view]
+    cfg = fr.Config.new(fr.Algo.Julia if algo == "julia" else fr.Algo.Mandelbrot)
     cfg.width = cfg.height = edge
-    cfg.iterations = args.iterations
+    cfg.iterations = iterations
     cfg.exposure = 5.0
-    if args.view == "default":
-        cfg.pos.re, cfg.pos.im = -0.6, 0.0
-    elif args.view == "zoom1e6":
-        cfg.pos.re, cfg.pos.im = -0.7436447860, 0.1318252536
-        cfg.scale.re = cfg.scale.im = 1e6
-    else:
-        cfg.julia_set.re, cfg.julia_set.im = -0.8, 0.156
+    cfg.pos.re, cfg.pos.im = pos
+    cfg.scale.re = cfg.scale.im = scale
+    if julia:
+        cfg.julia_set.re, cfg.julia_set.im = julia
     return cfg
 
 
-def cpu_baseline(cfg_bytes, precision, threads):
+def usable_cores():
+    """Cores this process can really use: the affinity mask, capped by the cgroup's CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def cpu_baseline(cfg_bytes, precision, threads, sample):
     """Time the CPU oracle (test infrastructure, used here ONLY as the reported baseline) on every
-    2nd pixel in x and y of the same workload.  Returns (dict, sampled colours, sampled Σ)."""
+    `sample`-th pixel in x and y of the same workload (1 = the whole image).  libm log2: what the
+    reference's f64::log2 calls.  Returns (rate dict, sampled colours, sampled Σ)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     ocfg = O.Config.from_buffer_copy(cfg_bytes)
-    sx = sy = 2
-    O.set_log2_mode(O.LOG2_SOFT)
-    try:
-        t0 = time.perf_counter()
-        total, npx, colours = O.sample_image(ocfg, sx, sy, precision, threads)
-        dt = time.perf_counter() - t0
-    finally:
-        O.set_log2_mode(O.LOG2_LIBM)
-    model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    info = {
-        "value": total / dt,
-        "unit": "pixel-iterations/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": "every 2nd pixel in x and y of the same image (%d pixels, %d pixel-iterations, %.2f s); "
-                  "oracle/fractal_oracle.c row-parallel driver, -O2 -ffp-contract=off" % (npx, total, dt),
-        "cpu_model": model,
-        "host_cores_online": os.cpu_count(),
+    O.set_log2_mode(O.LOG2_LIBM)
+    t0 = time.perf_counter()
+    total, npx, colours = O.sample_image(ocfg, sample, sample, precision, threads)
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "seconds": dt, "pixels": npx, "pixel_iterations": total, "threads": threads}, colours, total
+
+
+def roofline_block(prec_name, launch_px_it, kernel_ms, pixels, kernel_name, traffic):
+    peak = FP32_VECTOR_PEAK_TFLOPS if prec_name == "f32" else FP64_VECTOR_PEAK_TFLOPS
+    achieved = FLOPS_PER_ITERATION * launch_px_it / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    return {
+        "bound": "valu_f64" if prec_name == "f64" else "valu_f32",
+        "achieved": achieved,
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": achieved / peak,
+        "traffic": traffic,
+        "kernel": kernel_name,
+        "kernel_ms_avg": kernel_ms,
+        "algorithmic_flops_per_launch": FLOPS_PER_ITERATION * launch_px_it,
+        "hbm_check": {"algorithmic_bytes_per_launch": 3 * pixels,
+                      "achieved_GBps": 3 * pixels / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+                      "peak_GBps": 8000.0},
     }
-    return info, colours, total, (sx, sy)
+
+
+def traffic_record(cfg, prec_name, view):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get("%dx%d_i%d_%s_%s" % (cfg.width, cfg.height, cfg.iterations, prec_name, view))
+            return rec["hbm_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+ROOFLINE_NOTE = ("bound = VECTOR issue rate of the arithmetic type (no MFMA; not HBM: 3 B/pixel written once, see "
+                 "hbm_check); achieved = 10 flops (the reference's count per iteration) x executed pixel-iterations "
+                 "per launch / the kernel's HIP-event duration")
+
+
+class SingleGpu:
+    """One GPU, one process: the device-pointer API on torch's current stream."""
+
+    def __init__(self, torch, fr, lib, native, device):
+        self.torch, self.fr, self.lib, self.native, self.device = torch, fr, lib, native, device
+        self.stream = torch.cuda.current_stream(device)
+        self.image = None
+
+    def buffer(self, nbytes):
+        if self.image is None or self.image.numel() < nbytes:
+            self.image = None
+            self.image = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+        return self.image
+
+    def render(self, cfg, prec):
+        need = 3 * cfg.width * cfg.height
+        buf = self.buffer(need)
+        self.native.check(self.lib.fr_render_rows_rgb8_device(C.byref(cfg), int(prec), 0, cfg.height, buf.data_ptr(),
+                                                              need, self.stream.cuda_stream))
+        return buf[:need].view(cfg.height, cfg.width, 3)
+
+    def measure(self, cfg, prec, steps, warmup):
+        """W untimed + K timed renders of the whole image in one launch each.  Returns timings, the exact
+        executed-iteration sum and the name of the kernel that ran."""
+        torch, lib, native = self.torch, self.lib, self.native
+        native.check(lib.fr_set_profiling(1))
+        for _ in range(warmup):
+            self.render(cfg, prec)
+        torch.cuda.synchronize(self.device)
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            img = self.render(cfg, prec)
+            ms = C.c_float(0)
+            native.check(lib.fr_last_kernel_ms(C.byref(ms)))  # HIP events on the launch stream
+            kernel_ms.append(ms.value)
+        torch.cuda.synchronize(self.device)
+        dt = time.perf_counter() - t0
+        name = C.create_string_buffer(160)
+        native.check(lib.fr_last_kernel_name(name, len(name)))
+        total, _ = self.fr.count_iterations(cfg, 0, cfg.height, 1, 1, prec)
+        return {"dt": dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": sum(kernel_ms) / len(kernel_ms),
+                "total": total, "kernel": name.value.decode(), "image": img}
+
+
+def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup):
+    prec = fr.Precision.F32 if prec_name == "f32" else fr.Precision.F64
+    cfg = make_config(fr, view, 16384, iterations)
+    m = sg.measure(cfg, prec, steps, warmup)
+    pixels = cfg.width * cfg.height
+    return {
+        "workload": "%s 16384x16384 max_iter=%d %s view=%s (BASELINE %s)" % (VIEWS[view][0], iterations, prec_name, view, name),
+        "value": m["total"] * steps / m["dt"], "unit": "pixel-iterations/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": m["ms_per_step"], "dtype": prec_name, "pixel_iterations_per_image": m["total"],
+        "mean_iterations_per_pixel": m["total"] / pixels,
+        "roofline": roofline_block(prec_name, m["total"], m["kernel_ms"], pixels, m["kernel"] + " (fused coordinate map + "
+                                   "orbit loop + colour map)", traffic_record(cfg, prec_name, view)),
+    }
+
+
+def run_single(args, torch, fr, lib, native):
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    fr.init(0)
+    prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
+    edge = args.size or (65536 if args.workload == "c5" else 16384)
+    cfg = make_config(fr, args.view, edge, args.iterations)
+    pixels = cfg.width * cfg.height
+    sg = SingleGpu(torch, fr, lib, native, device)
+    is_c2 = (edge == 16384 and args.iterations == 1024 and args.view == "default" and args.precision == "f64")
+    label = "C2" if is_c2 else "C5's image on one GPU" if (edge == 65536 and args.view == "default") else "variant"
+
+    if args.force_blocks:
+        from fractal_renderer_amd import partition as P
+
+        renderer = P.DistributedRenderer(cfg, prec, args.block_rows, device=device, force_blocks=True)
+        for _ in range(args.warmup):
+            renderer.render()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = renderer.render()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        total, _ = fr.count_iterations(cfg, 0, cfg.height, 1, 1, prec)
+        m = {"dt": dt, "ms_per_step": dt / args.steps * 1e3, "kernel_ms": dt / args.steps * 1e3, "total": total,
+             "kernel": "block-by-block launches (tuning run)", "image": img}
+    else:
+        m = sg.measure(cfg, prec, args.steps, args.warmup)
+    total, img = m["total"], m["image"]
+    rate = total * args.steps / m["dt"]
+    out = {
+        "metric": "pixel_iterations_per_sec",
+        "value": rate,
+        "unit": "pixel-iterations/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "strong" if args.workload != "weak" else "weak",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic (deterministic: the image is a pure function of the Config)",
+        "config": {
+            "workload": "%s %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (
+                VIEWS[args.view][0], cfg.width, cfg.height, cfg.iterations, args.precision, args.view, label),
+            "per_gpu_pixels": pixels,
+            "partition": "one launch, whole image",
+            "exchange": "none",
+        },
+        "mpixels_per_sec": pixels * args.steps / m["dt"] / 1e6,
+        "pixel_iterations_per_image": total,
+        "kernel_ms_avg": m["kernel_ms"],
+        "build_id": fr.build_id(),
+        "roofline": dict(roofline_block(args.precision, total, m["kernel_ms"], pixels,
+                                        m["kernel"] + " (fused coordinate map + orbit loop + colour map)",
+                                        traffic_record(cfg, args.precision, args.view)), note=ROOFLINE_NOTE),
+    }
+    if args.no_extras:
+        print(json.dumps(out), flush=True)
+        return
+
+    ref = img.clone()
+    # t three ways (BASELINE.md §2): kernel only = kernel_ms_avg above; the drop-in call as the reference's
+    # caller sees it, into a host buffer that already exists (a GUI re-rendering), and into a FRESH one
+    # (get_image returns a new Vec every call, src/lib.rs:266-267): kernel + PCIe D2H, never `value`
+    import numpy as np
+
+    def host_call(buf):
+        th = time.perf_counter()
+        fr.get_image_rows(cfg, 0, cfg.height, prec, out=buf)
+        return (time.perf_counter() - th) * 1e3
+
+    hbuf = np.empty((cfg.height, cfg.width, 3), dtype=np.uint8)
+    host_call(hbuf)
+    resident = min(host_call(hbuf) for _ in range(3))
+    host_ok = bool((hbuf[::97] == ref[::97].cpu().numpy()).all())
+    del hbuf
+    fresh = []
+    for _ in range(3):
+        fbuf = np.empty((cfg.height, cfg.width, 3), dtype=np.uint8)  # never touched: no pages yet
+        fresh.append(host_call(fbuf))
+        del fbuf
+    out["end_to_end"] = {
+        "kernel_only_ms": m["kernel_ms"],
+        "resident_host_buffer_ms": resident,
+        "fresh_host_buffer_ms": min(fresh),
+        "fresh_host_buffer_ms_all": fresh,
+        "resident_value": total / (resident * 1e-3),
+        "fresh_value": total / (min(fresh) * 1e-3),
+        "bytes_identical_to_device_image_on_sampled_rows": host_ok,
+        "note": "fr_render_rows_rgb8 into a host buffer (kernel + D2H over PCIe, chunk-wise first touch + pin + DMA "
+                "overlapped with the rendering); the fresh-buffer time is what a drop-in get_image costs; not `value`",
+    }
+
+    # Extra, never the headline: the same steps with the exact periodicity shortcut on (bit-identical
+    # output, but periodic orbits are fast-forwarded instead of iterated, so it is not a roofline number)
+    if not args.cycle_shortcut:
+        native.check(lib.fr_set_cycle_shortcut(1))
+        sc = sg.measure(cfg, prec, max(2, args.steps // 2), 1)
+        out["exact_cycle_shortcut"] = {
+            "ms_per_step": sc["ms_per_step"], "value": total / (sc["ms_per_step"] * 1e-3),
+            "bytes_identical_to_plain_loop": bool(torch.equal(ref, sc["image"])), "kernel": sc["kernel"],
+            "note": "fr_set_cycle_shortcut(1): orbits that return bitwise to an earlier state are fast-forwarded to "
+                    "the cap; same bytes, fewer iterations executed; off by default, excluded from `value` and `roofline`"}
+        native.check(lib.fr_set_cycle_shortcut(0))
+
+    # the other single-GPU BASELINE configs, driver-timed in the same run (C3 is ~1.2 s a step: 2 steps)
+    if is_c2:
+        out["other_configs"] = {
+            "C3": other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1),
+            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 2),
+            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2),
+            "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
+        }
+        img = sg.render(cfg, prec)  # the shared device buffer held the other configs meanwhile
+        torch.cuda.synchronize(device)
+
+    if not args.no_cpu_baseline:
+        cores = usable_cores()
+        threads = args.cpu_threads or cores
+        # the whole image when that is ~10-30 s of CPU work, else a regular sub-sample of it
+        est_rate = 5.5e8 * threads
+        sample = 1
+        while total / (sample * sample) / est_rate > 30.0:
+            sample *= 2
+        info, colours, cpu_total = cpu_baseline(bytes(cfg), int(prec), threads, sample)
+        got = img[::sample, ::sample].cpu().numpy()
+        gpu_total, _ = fr.count_iterations(cfg, 0, cfg.height, sample, sample, prec)
+        base = {
+            "value": info["value"],
+            "unit": "pixel-iterations/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": ("the whole image" if sample == 1 else "every %d-th pixel in x and y of the same image" % sample)
+                      + " (%d pixels, %d pixel-iterations, %.2f s); oracle/fractal_oracle.c row-parallel driver "
+                        "(dynamic row scheduling, like the reference's rayon loop), -O2 -ffp-contract=off, libm log2"
+                      % (info["pixels"], info["pixel_iterations"], info["seconds"]),
+            "cpu_model": cpu_model(),
+            "host_cores_online": os.cpu_count(),
+            "cores_usable_by_this_process": cores,
+            "gpu_bytes_identical_on_sample": bool((got == colours).all()),
+            "gpu_iteration_sum_identical_on_sample": bool(gpu_total == cpu_total),
+        }
+        if threads > 16:
+            i16, _, _ = cpu_baseline(bytes(cfg), int(prec), 16, max(sample, 2))
+            base["value_16_threads"] = i16["value"]
+        out["cpu_baseline"] = base
+        out["gpu_over_cpu"] = rate / info["value"]
+    print(json.dumps(out), flush=True)
+
+
+def workload_edge(args, world):
+    if args.size:
+        return args.size
+    if args.workload == "c5":
+        return 65536
+    if args.workload == "weak":
+        return int(round(16384 * math.sqrt(world)))
+    return 16384
+
+
+def workload_label(args, world, edge):
+    if args.view == "default" and args.iterations == 1024 and args.precision == "f64":
+        if edge == 16384:
+            return "C2's image split over %d GPUs" % world
+        if edge == 65536:
+            return "C5" if world == 8 else "C5's image over %d GPUs" % world
+        if args.workload == "weak":
+            return "C2-shaped, weak-scaled"
+    return "variant"
+
+
+def run_in_library(args, torch, fr, lib, native):
+    """Plain `python3 bench.py --gpus N`: one process, N GPUs, through fr_init_devices."""
+    world = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev < world and not args.logical:
+        print(json.dumps({
+            "metric": "pixel_iterations_per_sec", "value": None, "unit": "pixel-iterations/s", "n_gpus": world,
+            "error": "needs %d devices, this box has %d (add --logical for %d logical devices on GPU 0: a plumbing "
+                     "check, not a scaling number)" % (world, ndev, world),
+            "devices_visible": ndev}), flush=True)
+        return
+    devices = [0] * world if ndev < world else list(range(world))
+    logical = ndev < world
+    import numpy as np
+
+    torch.cuda.set_device(devices[0])
+    fr.init(devices[0])
+    fr.init_devices(devices)
+    prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
+    edge = workload_edge(args, world)
+    cfg = make_config(fr, args.view, edge, args.iterations)
+    need = 3 * cfg.width * cfg.height
+    gather = native.FR_GATHER_PEER_COPY if (args.gather == "peer" or logical) else native.FR_GATHER_RCCL
+    d_img = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", devices[0]))
+
+    def step():
+        native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), int(prec), args.block_rows, gather, d_img.data_ptr(), need))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # returns when the whole image is in the first GPU's HBM
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = fr.multi_stats()
+    total, _ = fr.count_iterations(cfg, 0, cfg.height, 1, 1, prec)
+    # the host-buffer variant: every GPU DMAs its blocks to the caller's buffer over its own PCIe link
+    hbuf = np.empty((cfg.height, cfg.width, 3), dtype=np.uint8)
+    fr.get_image_multi(cfg, prec, args.block_rows, out=hbuf)
+    th = time.perf_counter()
+    fr.get_image_multi(cfg, prec, args.block_rows, out=hbuf)
+    host_ms = (time.perf_counter() - th) * 1e3
+    same = bool((hbuf[::61] == d_img.view(cfg.height, cfg.width, 3)[::61].cpu().numpy()).all())
+    kmax = max(st["kernel_ms"])
+    pixels = cfg.width * cfg.height
+    out = {
+        "metric": "pixel_iterations_per_sec", "value": total * args.steps / dt, "unit": "pixel-iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak" if args.workload == "weak" else "strong", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic (deterministic: the image is a pure function of the Config)",
+        "config": {
+            "workload": "%s %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (
+                VIEWS[args.view][0], cfg.width, cfg.height, cfg.iterations, args.precision, args.view,
+                workload_label(args, world, edge)),
+            "per_gpu_pixels": pixels // world,
+            "partition": "row-block-cyclic, %d-row blocks, %d devices, ONE process (fr_init_devices: one host thread "
+                         "+ streams per device)" % (args.block_rows, world),
+            "exchange": ("grouped ncclSend/ncclRecv (ncclCommInitAll)" if gather == native.FR_GATHER_RCCL else
+                         "peer-to-peer DMA (hipMemcpyPeerAsync)") + " of finished row blocks to the first device, "
+                        "pipelined behind the rendering, inside the timed step",
+            "logical_devices_on_one_gpu": logical,
+        },
+        "mpixels_per_sec": pixels * args.steps / dt / 1e6,
+        "pixel_iterations_per_image": total,
+        "per_device_kernel_ms": st["kernel_ms"],
+        "build_id": fr.build_id(),
+        "roofline": dict(roofline_block(args.precision, total / world, kmax, pixels // world,
+                                        "escape kernels of the slowest device's share (summed over its chunk launches)",
+                                        None), note=ROOFLINE_NOTE),
+        "host_buffer_variant": {"ms": host_ms, "value": total / (host_ms * 1e-3), "bytes_identical_to_gathered_image": same,
+                                "note": "fr_render_rgb8_multi: each device DMAs its blocks straight to their place in the "
+                                        "caller's pinned host buffer over its own PCIe link; resident buffer"},
+    }
+    if logical:
+        out["note"] = "logical devices share ONE GPU: this line checks the plumbing and is not a scaling measurement"
+    print(json.dumps(out), flush=True)
+
+
+def run_distributed(args, torch, fr, lib, native, world, rank, local_rank):
+    """Under a launcher: one process per GPU, torch.distributed point-to-point (= RCCL) gather."""
+    import torch.distributed as dist
+
+    from fractal_renderer_amd import partition as P
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    fr.init(local_rank)
+    prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
+    edge = workload_edge(args, world)
+    cfg = make_config(fr, args.view, edge, args.iterations)
+    row_bytes = 3 * cfg.width
+    B = args.block_rows
+    renderer = P.DistributedRenderer(cfg, prec, B, device=device)
+    stream = torch.cuda.current_stream(device)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        renderer.render()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        renderer.render()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    # the dominant kernel's duration for the roofline: this rank's whole share as ONE launch, timed
+    # with HIP events outside the timed region (the step itself launches per chunk of blocks)
+    share = torch.empty(max(P.local_rows(cfg.height, B, rank, world) * row_bytes, 1), dtype=torch.uint8, device=device)
+    native.check(lib.fr_set_profiling(1))
+    kernel_ms = []
+    for _ in range(3):
+        P.render_local_hip(cfg, prec, B, rank, world, share, stream.cuda_stream)
+        ms = C.c_float(0)
+        native.check(lib.fr_last_kernel_ms(C.byref(ms)))
+        kernel_ms.append(ms.value)
+    name = C.create_string_buffer(160)
+    native.check(lib.fr_last_kernel_name(name, len(name)))
+    del share
+    y0 = cfg.height * rank // world
+    y1 = cfg.height * (rank + 1) // world
+    total, _ = fr.count_iterations(cfg, y0, y1, 1, 1, prec)
+    t = torch.tensor([total], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    total = int(t.item())
+    k = torch.tensor([sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=device)
+    dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    kavg = float(k.item())
+    if rank == 0:
+        pixels = cfg.width * cfg.height
+        out = {
+            "metric": "pixel_iterations_per_sec", "value": total * args.steps / dt, "unit": "pixel-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak" if args.workload == "weak" else "strong", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic (deterministic: the image is a pure function of the Config)",
+            "config": {
+                "workload": "%s %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (
+                    VIEWS[args.view][0], cfg.width, cfg.height, cfg.iterations, args.precision, args.view,
+                    workload_label(args, world, edge)),
+                "per_gpu_pixels": pixels // world,
+                "partition": "row-block-cyclic, %d-row blocks, %d ranks (one process per GPU)" % (B, world),
+                "exchange": "RCCL point-to-point gather of finished row blocks to rank 0, pipelined behind the "
+                            "rendering, inside the timed step",
+            },
+            "mpixels_per_sec": pixels * args.steps / dt / 1e6,
+            "pixel_iterations_per_image": total,
+            "kernel_ms_avg": kavg,
+            "build_id": fr.build_id(),
+            "roofline": dict(roofline_block(args.precision, total / world, kavg, pixels // world,
+                                            name.value.decode() + " over one rank's whole share (slowest rank)", None),
+                             note=ROOFLINE_NOTE),
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -115,223 +572,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    launched = "RANK" in os.environ and world > 1
 
     import torch  # first: the library then shares torch's HIP runtime
-    import torch.distributed as dist
 
     import fractal_renderer_amd as fr
     from fractal_renderer_amd import _native
-    from fractal_renderer_amd import partition as P
 
     if not torch.cuda.is_available():
+        if args.gpus > 1:
+            print(json.dumps({"metric": "pixel_iterations_per_sec", "value": None, "n_gpus": args.gpus,
+                              "error": "needs %d devices, this box has 0 (there is no CPU fallback)" % args.gpus}), flush=True)
+            return
         sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    fr.init(local_rank)
     lib = _native.load()
     _native.check(lib.fr_set_tile(args.tile))
     _native.check(lib.fr_set_loop_mode(args.loop_mode))
+    _native.check(lib.fr_set_colour_filter(0 if args.no_colour_filter else 1))
     if args.cycle_shortcut:
         _native.check(lib.fr_set_cycle_shortcut(1))
     if args.refill:
         mr, q16 = (int(v) for v in args.refill.split(","))
         _native.check(lib.fr_set_refill_policy(mr, q16))
-    device = torch.device("cuda", local_rank)
-    prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
-
-    edge = int(round(args.size * math.sqrt(world)))
-    cfg = make_config(fr, args, edge)
-    row_bytes = 3 * cfg.width
-    B = args.block_rows
-    renderer = P.DistributedRenderer(cfg, prec, B, device=device, force_blocks=args.force_blocks)
-    stream = torch.cuda.current_stream(device)
-
-    kernel_ms = []
-
-    def step(record):
-        # N = 1: one launch renders the whole image in place; N > 1: one launch per owned row block,
-        # each block sent to rank 0 while the next one renders (partition.DistributedRenderer)
-        img = renderer.render()
-        if record and world == 1 and not args.force_blocks:
-            ms = C.c_float(0)
-            _native.check(lib.fr_last_kernel_ms(C.byref(ms)))  # HIP events on the launch stream
-            kernel_ms.append(ms.value)
-        return img
-
-    def fence():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    _native.check(lib.fr_set_profiling(1 if world == 1 else 0))
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    img = None
-    for _ in range(args.steps):
-        img = step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # the dominant kernel's duration for the roofline: this rank's whole share as ONE launch,
-        # timed with HIP events outside the timed region (the step itself launches per block)
-        share = torch.empty(max(P.local_rows(cfg.height, B, rank, world) * row_bytes, 1), dtype=torch.uint8,
-                            device=device)
-        _native.check(lib.fr_set_profiling(1))
-        for _ in range(3):
-            P.render_local_hip(cfg, prec, B, rank, world, share, stream.cuda_stream)
-            ms = C.c_float(0)
-            _native.check(lib.fr_last_kernel_ms(C.byref(ms)))
-            kernel_ms.append(ms.value)
-        del share
-
-    # Extra, never the headline: the same steps with the exact periodicity shortcut on (bit-identical
-    # output, but periodic orbits are fast-forwarded instead of iterated, so it is not a roofline number)
-    shortcut = None
-    if world == 1 and not args.cycle_shortcut:
-        _native.check(lib.fr_set_cycle_shortcut(1))
-        _native.check(lib.fr_set_profiling(0))
-        ref = img.clone() if img is not None else None
-        renderer.render()
-        fence()
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            img2 = renderer.render()
-        fence()
-        shortcut = {"ms_per_step": (time.perf_counter() - ts) / args.steps * 1e3,
-                    "bytes_identical_to_plain_loop": bool(torch.equal(ref, img2))}
-        _native.check(lib.fr_set_cycle_shortcut(0))
-        _native.check(lib.fr_set_profiling(1))
-        img = ref
-
-    # Extra, never the headline: the drop-in call as the reference's caller sees it — fr_render_rows_rgb8
-    # into a HOST buffer (kernel + PCIe D2H, pinned + band-pipelined), second call into the same buffer
-    host_call = None
-    if world == 1 and rank == 0:
-        import numpy as np
-
-        hbuf = np.empty((cfg.height, cfg.width, 3), dtype=np.uint8)
-        fr.get_image_rows(cfg, 0, cfg.height, prec, out=hbuf)
-        th = time.perf_counter()
-        fr.get_image_rows(cfg, 0, cfg.height, prec, out=hbuf)
-        host_call = {"ms": (time.perf_counter() - th) * 1e3,
-                     "note": "fr_render_rows_rgb8 into a resident host buffer: kernel + D2H over PCIe; not `value`"}
-        del hbuf
-
-    # exact Σ executed iterations of the whole image, counted on the device outside the timed region
-    y0 = cfg.height * rank // world
-    y1 = cfg.height * (rank + 1) // world
-    total, _ = fr.count_iterations(cfg, y0, y1, 1, 1, prec)
-    kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
-    my_px_it = None
-    if world > 1:
-        t = torch.tensor([total], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total = int(t.item())
-        k = torch.tensor([kavg], dtype=torch.float64, device=device)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kavg = float(k.item())
-
-    if rank == 0:
-        pixels = cfg.width * cfg.height
-        rate = total * args.steps / dt
-        peak = FP32_VECTOR_PEAK_TFLOPS if args.precision == "f32" else FP64_VECTOR_PEAK_TFLOPS
-        # the dominant kernel: per launch it executes this rank's share of the pixel-iterations
-        launch_px_it = total / world
-        achieved = FLOPS_PER_ITERATION * launch_px_it / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                rec = json.load(f).get("%dx%d_i%d_%s_%s" % (cfg.width, cfg.height, cfg.iterations, args.precision, args.view))
-                if rec:
-                    traffic = rec["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        out = {
-            "metric": "pixel_iterations_per_sec",
-            "value": rate,
-            "unit": "pixel-iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.precision,
-            "data": "synthetic (deterministic: the image is a pure function of the Config)",
-            "config": {
-                "workload": "mandelbrot %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (
-                    cfg.width, cfg.height, cfg.iterations, args.precision, args.view,
-                    "C2" if (world == 1 and args.size == 16384 and args.iterations == 1024 and args.view == "default"
-                             and args.precision == "f64") else "C2-shaped, weak-scaled" if args.view == "default" else "variant"),
-                "per_gpu_pixels": pixels // world,
-                "partition": "row-block-cyclic, %d-row blocks, %d ranks" % (B, world),
-                "exchange": "none" if world == 1 else "RCCL point-to-point gather of finished row blocks to rank 0, "
-                                                      "pipelined behind the rendering, inside the timed step",
-            },
-            "mpixels_per_sec": pixels * args.steps / dt / 1e6,
-            "pixel_iterations_per_image": total,
-            "kernel_ms_avg": kavg,
-            "roofline": {
-                "bound": "valu_f64" if args.precision == "f64" else "valu_f32",
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                "traffic": traffic,
-                "kernel": "escape_strip_kernel<%s, RGB, 7 tiles> (fused coordinate map + orbit loop + colour map)"
-                          % ("double" if args.precision == "f64" else "float"),
-                "algorithmic_flops_per_launch": FLOPS_PER_ITERATION * launch_px_it,
-                "frac_of_attainable_no_fma": (VALU_OPS_PER_ITERATION * launch_px_it / (kavg * 1e-3)) / (peak / 2 * 1e12)
-                if kavg > 0 else 0.0,
-                # the loop's own share of the SIMDs' issue slots at the nominal clock: 6.5 VALU instructions
-                # per iteration (scaled loop, escape check every 4th), each 4 cycles per wave64 for f64
-                # (measured: tools/ubench/valu_rates.hip), 1024 SIMDs at 2.4 GHz
-                "loop_valu_issue_frac": (6.5 * launch_px_it / 64 * (4 if args.precision == "f64" else 2))
-                / (kavg * 1e-3 * 2.4e9 * 1024) if kavg > 0 else 0.0,
-                "hbm_check": {"algorithmic_bytes_per_launch": 3 * pixels // world,
-                              "achieved_GBps": 3 * pixels / world / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0,
-                              "peak_GBps": 8000.0},
-                "note": "bound = fp64 VECTOR issue rate (no MFMA; not HBM: 3 B/pixel written once, see hbm_check). "
-                        "frac_of_attainable_no_fma prices SURVEY.md's 8-VALU-op iteration without FMA (peak/2 "
-                        "lane-ops/s); the scaled loop issues 6.5 per iteration, so that figure is not a ceiling.",
-            },
-        }
-        if host_call is not None:
-            host_call["value"] = total / (host_call["ms"] * 1e-3)
-            out["end_to_end_host_buffer"] = host_call
-        if shortcut is not None:
-            shortcut["value"] = total / (shortcut["ms_per_step"] * 1e-3)
-            shortcut["note"] = ("fr_set_cycle_shortcut(1): orbits that return bitwise to an earlier state are "
-                                "fast-forwarded to the cap; same bytes, fewer iterations executed; off by default "
-                                "and excluded from `value` and `roofline`")
-            out["exact_cycle_shortcut"] = shortcut
-        if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
-            info, colours, cpu_total, (sx, sy) = cpu_baseline(bytes(cfg), int(prec), threads)
-            # byte-compare the GPU image with the CPU path on the sampled pixels, same run
-            got = img[::sy, ::sx].cpu().numpy()
-            gpu_total, _ = fr.count_iterations(cfg, 0, cfg.height, sx, sy, prec)
-            info["gpu_bytes_identical_on_sample"] = bool((got == colours).all())
-            info["gpu_iteration_sum_identical_on_sample"] = bool(gpu_total == cpu_total)
-            out["cpu_baseline"] = info
-            out["gpu_over_cpu"] = rate / info["value"]
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if launched:
+        args.gpus = world
+        run_distributed(args, torch, fr, lib, _native, world, rank, local_rank)
+    elif args.gpus > 1:
+        run_in_library(args, torch, fr, lib, _native)
+    else:
+        run_single(args, torch, fr, lib, _native)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,7 @@ __all__ = [
     "Algo", "Config", "Imaginary", "RGB", "Precision", "FractalHipError",
     "get_image", "get_image_rows", "get_image_rgba", "get_recursive_pixel", "recursive", "recursive_batch",
     "escape_rows", "colour_image", "count_iterations", "init", "shutdown", "device_count", "device_name",
+    "RenderOpts", "init_devices", "get_image_multi", "multi_stats", "build_id",
 ]
 
 
@@ -71,6 +72,47 @@ class Config(_native.fr_config):
         return other
 
 
+class RenderOpts(_native.fr_render_opts):
+    """fr_render_opts: implementation selectors of ONE call (none changes an output byte).
+    RenderOpts(tile=9, cycle_shortcut=1) starts from the process defaults."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        _native.load().fr_render_opts_init(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_) or k == "size":
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+def build_id():
+    return _native.load().fr_build_id().decode()
+
+
+def init_devices(devices):
+    """fr_init_devices: the device set of the multi-GPU get_image; an index may repeat (logical devices)."""
+    arr = (C.c_int * len(devices))(*devices)
+    _native.check(_native.load().fr_init_devices(arr, len(devices)))
+
+
+def get_image_multi(config, precision=0, block_rows=0, out=None):
+    """get_image across the device set into a host array: every device DMAs its row blocks to their
+    final place (fr_render_rgb8_multi)."""
+    if out is None:
+        out = np.empty((config.height, config.width, 3), dtype=np.uint8)
+    _native.check(_native.load().fr_render_rgb8_multi(C.byref(config), int(precision), block_rows, out.ctypes.data,
+                                                      out.nbytes))
+    return out
+
+
+def multi_stats():
+    st = _native.fr_multi_stats()
+    _native.check(_native.load().fr_multi_last_stats(C.byref(st)))
+    n = st.n_devices
+    return {"n_devices": n, "kernels": list(st.kernels[:n]), "kernel_ms": list(st.kernel_ms[:n]),
+            "rows": list(st.rows[:n]), "wall_ms": st.wall_ms}
+
+
 def init(device=-1):
     _native.check(_native.load().fr_init(device))
 
@@ -91,13 +133,14 @@ def device_name():
     return buf.value.decode()
 
 
-def get_image_rows(config, y0, y1, precision=Precision.F64, out=None):
+def get_image_rows(config, y0, y1, precision=Precision.F64, out=None, opts=None):
     """Rows [y0, y1) of get_image — the unit of the reference's rayon loop (src/lib.rs:256-264).
     Returns uint8 [y1-y0, width, 3]."""
     if out is None:
         out = np.empty((max(int(y1) - int(y0), 0), config.width, 3), dtype=np.uint8)
     _native.check(
-        _native.load().fr_render_rows_rgb8(C.byref(config), int(precision), y0, y1, out.ctypes.data, out.nbytes)
+        _native.load().fr_render_rows_rgb8_opts(C.byref(config), int(precision), y0, y1, out.ctypes.data, out.nbytes,
+                                                C.byref(opts) if opts is not None else None)
     )
     return out
 

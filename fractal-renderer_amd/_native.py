@@ -76,9 +76,66 @@ class fr_config(C.Structure):
     ]
 
 
+class fr_render_opts(C.Structure):
+    """include/fractal_hip.h fr_render_opts: the implementation selectors of ONE call."""
+
+    _fields_ = [
+        ("size", C.c_uint32),
+        ("tile", C.c_int32),
+        ("loop_mode", C.c_int32),
+        ("palette", C.c_int32),
+        ("cycle_shortcut", C.c_int32),
+        ("refill_minrun", C.c_int32),
+        ("refill_quit16", C.c_int32),
+        ("colour_filter", C.c_int32),
+    ]
+
+
+FR_MAX_DEVICES = 16
+FR_GATHER_PEER_COPY, FR_GATHER_RCCL = 0, 1
+
+
+class fr_multi_stats(C.Structure):
+    _fields_ = [
+        ("n_devices", C.c_uint32),
+        ("kernels", C.c_uint32 * FR_MAX_DEVICES),
+        ("kernel_ms", C.c_float * FR_MAX_DEVICES),
+        ("rows", C.c_uint64 * FR_MAX_DEVICES),
+        ("wall_ms", C.c_double),
+    ]
+
+
+_OPTS = C.POINTER(fr_render_opts)
+
 # name -> (restype, argtypes); every symbol include/fractal_hip.h declares
 PROTOTYPES = {
     "fr_abi_version": (C.c_int, []),
+    "fr_build_id": (C.c_char_p, []),
+    "fr_render_opts_init": (None, [_OPTS]),
+    "fr_render_rows_rgb8_device_opts": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, _OPTS],
+    ),
+    "fr_render_rows_rgba8_device_opts": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, _OPTS],
+    ),
+    "fr_render_rows_rgb8_opts": (
+        C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, _OPTS]),
+    "fr_render_block_cyclic_range_rgb8_device_opts": (
+        C.c_int,
+        [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+         C.c_void_p, C.POINTER(C.c_uint64), _OPTS],
+    ),
+    "fr_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "fr_multi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "fr_render_rgb8_multi": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "fr_render_rgb8_multi_device": (
+        C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]),
+    "fr_multi_last_stats": (C.c_int, [C.POINTER(fr_multi_stats)]),
+    "fr_debug_rccl_selftest": (C.c_int, [C.c_size_t]),
+    "fr_last_kernel_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "fr_set_colour_filter": (C.c_int, [C.c_int]),
     "fr_init": (C.c_int, [C.c_int]),
     "fr_shutdown": (C.c_int, []),
     "fr_device_count": (C.c_int, [C.POINTER(C.c_int)]),

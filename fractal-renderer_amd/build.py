@@ -2,7 +2,12 @@
 
 -ffp-contract=off is REQUIRED for bit parity with the reference (Rust never fuses a*b+c); see
 csrc/fr_kernels.hip.
+
+Staleness is decided by CONTENT: the SHA-256 of every source, header and flag is compiled into the
+library (fr_build_id()) and kept beside it in libfractal_hip.so.id, so "which sources was the .so that
+ran the tests built from" has an unambiguous answer (bench.py prints it).
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -10,8 +15,10 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfractal_hip.so")
-SOURCES = ["fr_kernels.hip", "fr_api.hip"]
-DEPS = SOURCES + ["fr_kernels.h", "fr_math.h", "fr_log2_table.inc", os.path.join("..", "..", "include", "fractal_hip.h")]
+ID_PATH = LIB_PATH + ".id"
+SOURCES = ["fr_kernels.hip", "fr_api.hip", "fr_host.hip", "fr_multi.hip"]
+DEPS = SOURCES + ["fr_kernels.h", "fr_ctx.h", "fr_math.h", "fr_log2_table.inc",
+                  os.path.join("..", "..", "include", "fractal_hip.h")]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -22,7 +29,9 @@ HIPCC_FLAGS = [
     "-shared",
     "-Wall",
     "-Wextra",
+    "-pthread",
 ]
+LINK_FLAGS = ["-ldl"]
 
 
 def find_hipcc():
@@ -32,21 +41,43 @@ def find_hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_id():
+    """SHA-256 (first 16 hex digits) over the flags and the content of every file the library is built from."""
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS + LINK_FLAGS).encode())
+    for d in DEPS:
+        h.update(d.encode())
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_id():
+    try:
+        with open(ID_PATH) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS) or os.path.getmtime(__file__) > t
+    return not os.path.exists(LIB_PATH) or built_id() != source_id()
 
 
 def build_extension(force=False, verbose=False):
     """Compile csrc/*.hip into libfractal_hip.so.  Returns the path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    sid = source_id()
+    cmd = ([find_hipcc()] + HIPCC_FLAGS + ['-DFR_BUILD_ID="%s"' % sid, "-o", LIB_PATH]
+           + [os.path.join(CSRC, s) for s in SOURCES] + LINK_FLAGS)
     if verbose:
         print(" ".join(cmd))
+    if os.path.exists(ID_PATH):
+        os.remove(ID_PATH)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(ID_PATH, "w") as f:
+        f.write(sid + "\n")
     return LIB_PATH
 
 

@@ -15,52 +15,58 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
-#include "../../include/fractal_hip.h"
-#include "fr_kernels.h"
+#include "fr_ctx.h"
 
 static_assert(sizeof(fr_config) == 104 && offsetof(fr_config, limit) == 16 && offsetof(fr_config, inside) == 72 &&
                   offsetof(fr_config, primary_color) == 74 && offsetof(fr_config, color_weight) == 80 &&
                   offsetof(fr_config, julia_set) == 88,
               "fr_config must stay the #[repr(C)] image of calc::Config");
+static_assert(sizeof(fr_render_opts) == 32, "fr_render_opts is part of the ABI");
+
+namespace fr {
 
 namespace {
 
 thread_local std::string tl_error;
-
-struct Profiling {
-    bool enabled = false;
-    bool have = false;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-};
 thread_local Profiling tl_prof;
+std::atomic<bool> g_process_exiting{false};
 
-struct Scratch {
-    void *ptr = nullptr;
-    size_t cap = 0;
-};
+std::shared_mutex g_life;
+std::mutex g_primary_mu; /* creation / switch of the primary context */
+Ctx g_primary;
+bool g_primary_inited = false;
 
-struct State {
-    std::mutex mu; /* serialises the host-buffer entry points (they share stream + scratch) */
-    bool inited = false;
-    int device = 0;
-    hipStream_t stream = nullptr;      /* kernels of the host-buffer entry points */
-    hipStream_t copy_stream = nullptr; /* their D2H copies, overlapped with the next band's kernel */
-    std::vector<hipEvent_t> band_done;
-    Scratch rgb, z, iters, misc;
-};
-State g;
+/* process-wide defaults of the per-call selectors (fr_set_*) */
 std::atomic<int> g_tile{0};
 std::atomic<int> g_palette_enabled{1};
 std::atomic<int> g_cycle_shortcut{0};
 std::atomic<int> g_refill_minrun{32}, g_refill_quit16{8};
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
+std::atomic<int> g_colour_filter{1};
+
+bool valid_tile(int tile) {
+    switch (tile) {
+    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 6401: case 3202: case 1604: case 808:
+        return true;
+    default:
+        return false;
+    }
+}
+
+}  // namespace
 
 int fail(int code, const char *what) {
+    tl_error = what;
+    return code;
+}
+int fail(int code, const std::string &what) {
     tl_error = what;
     return code;
 }
@@ -73,110 +79,95 @@ int fail_hip(hipError_t e, const char *what) {
     return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? FR_ERR_NO_DEVICE : FR_ERR_HIP;
 }
 
-#define HIP_TRY(expr)                                         \
-    do {                                                      \
-        hipError_t e_ = (expr);                               \
-        if (e_ != hipSuccess) return fail_hip(e_, #expr);     \
-    } while (0)
+const std::string &last_error() { return tl_error; }
 
-/* Palette scratch for smooth == false renders: a small ring of device buffers owned by the library
- * (no allocation on the render path, usable from any stream).  A slot is handed out only after the
- * event recorded behind its last user has completed. */
-struct PaletteSlot {
-    uint32_t *dev = nullptr;
-    hipEvent_t done = nullptr;
-    bool pending = false; /* `done` was recorded and not yet waited for */
-    std::atomic<bool> busy{false};
-};
-constexpr int kPaletteSlots = 16;
-PaletteSlot g_palette_slots[kPaletteSlots];
-std::mutex g_palette_mu;
-unsigned g_palette_next = 0;
+LifeShared::LifeShared() { g_life.lock_shared(); }
+LifeShared::~LifeShared() { g_life.unlock_shared(); }
+LifeExclusive::LifeExclusive() { g_life.lock(); }
+LifeExclusive::~LifeExclusive() { g_life.unlock(); }
 
-int acquire_palette_slot(PaletteSlot **out) {
-    std::lock_guard<std::mutex> lk(g_palette_mu);
-    for (int tries = 0; tries < kPaletteSlots; tries++) {
-        PaletteSlot &s = g_palette_slots[g_palette_next++ % kPaletteSlots];
-        if (s.busy.load()) continue; /* another thread is between acquire and its event record */
-        if (!s.dev) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * FR_MAX_PALETTE_ENTRIES));
-            HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        }
-        if (s.pending) {
-            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if 16 renders are in flight */
-            s.pending = false;
-        }
-        s.busy.store(true);
-        *out = &s;
-        return FR_OK;
+Profiling &profiling() { return tl_prof; }
+Profiling::~Profiling() {
+    /* a thread that profiled gives its two events back — unless the process is already tearing the
+     * HIP runtime down (static destruction order is not ours to rely on) */
+    if (e0 && !g_process_exiting.load()) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
     }
-    return fail(FR_ERR_HIP, "no palette slot available");
+    e0 = e1 = nullptr;
 }
 
-/* called with g.mu held, when the library leaves a device */
-void release_palette_slots() {
-    std::lock_guard<std::mutex> pl(g_palette_mu);
-    for (PaletteSlot &ps : g_palette_slots) {
-        if (ps.done) (void)hipEventDestroy(ps.done);
-        if (ps.dev) (void)hipFree(ps.dev);
-        ps.dev = nullptr;
-        ps.done = nullptr;
-        ps.pending = false;
-        ps.busy.store(false);
-    }
+Opts default_opts() {
+    Opts o;
+    o.tile = g_tile.load();
+    o.loop_mode = g_loop_mode.load();
+    o.palette = g_palette_enabled.load();
+    o.cycle_shortcut = g_cycle_shortcut.load();
+    o.refill_minrun = g_refill_minrun.load();
+    o.refill_quit16 = g_refill_quit16.load();
+    o.colour_filter = g_colour_filter.load();
+    return o;
 }
 
-/* caller holds g.mu */
-void release_streams_locked() {
-    for (hipEvent_t e : g.band_done) (void)hipEventDestroy(e);
-    g.band_done.clear();
-    if (g.stream) (void)hipStreamDestroy(g.stream);
-    if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
-    g.stream = nullptr;
-    g.copy_stream = nullptr;
+int resolve_opts(const fr_render_opts *in, Opts &o) {
+    o = default_opts();
+    if (!in) return FR_OK;
+    if (in->size < sizeof(fr_render_opts)) return fail(FR_ERR_INVALID_ARGUMENT, "fr_render_opts.size is too small (use fr_render_opts_init)");
+    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 6401, 3202, 1604 or 808");
+    if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
+        return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
+    if (in->refill_minrun < 0 || in->refill_quit16 < 1 || in->refill_quit16 > 16)
+        return fail(FR_ERR_INVALID_ARGUMENT, "opts: refill_minrun >= 0, 1 <= refill_quit16 <= 16");
+    o.tile = in->tile;
+    o.loop_mode = in->loop_mode;
+    o.palette = in->palette != 0;
+    o.cycle_shortcut = in->cycle_shortcut != 0;
+    o.refill_minrun = in->refill_minrun;
+    o.refill_quit16 = in->refill_quit16;
+    o.colour_filter = in->colour_filter != 0;
+    return FR_OK;
 }
 
-/* caller holds g.mu */
-int init_locked(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        return fail(FR_ERR_NO_DEVICE, "no HIP device available (libfractal_hip has no CPU fallback)");
-    }
-    if (device < 0) device = g.inited ? g.device : 0;
-    if (device >= n) return fail(FR_ERR_NO_DEVICE, "device index out of range");
-    if (g.inited && g.device == device) return FR_OK;
-    if (g.inited) {
-        /* switching device: drop state that lives on the old one */
-        (void)hipSetDevice(g.device);
-        for (Scratch *s : {&g.rgb, &g.z, &g.iters, &g.misc}) {
-            if (s->ptr) (void)hipFree(s->ptr);
-            *s = Scratch();
-        }
-        release_streams_locked();
-        release_palette_slots();
-        g.inited = false;
-    }
+/* ---- Ctx --------------------------------------------------------------------------------------- */
+
+int Ctx::create(int device) {
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
-    g.device = device;
-    g.inited = true;
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    hip_device = device;
     return FR_OK;
 }
 
-/* caller holds g.mu; hipSetDevice is per host thread, so every entry point re-asserts it */
-int ensure_locked() {
-    if (!g.inited) {
-        int rc = init_locked(-1);
-        if (rc != FR_OK) return rc;
+void Ctx::destroy() {
+    if (hip_device < 0) return;
+    (void)hipSetDevice(hip_device);
+    /* hipFree waits for the device, so nothing below can still be in use by a kernel in flight */
+    for (Scratch *s : {&rgb, &z, &iters, &misc}) {
+        if (s->ptr) (void)hipFree(s->ptr);
+        *s = Scratch();
     }
-    HIP_TRY(hipSetDevice(g.device));
-    return FR_OK;
+    {
+        std::lock_guard<std::mutex> pl(palette_mu);
+        for (PaletteSlot &ps : palette_slots) {
+            if (ps.dev) (void)hipFree(ps.dev);
+            if (ps.done) (void)hipEventDestroy(ps.done);
+            ps = PaletteSlot();
+        }
+    }
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    events.clear();
+    for (hipStream_t *st : {&stream, &stream2, &copy_stream}) {
+        if (*st) {
+            (void)hipStreamSynchronize(*st);
+            (void)hipStreamDestroy(*st);
+        }
+        *st = nullptr;
+    }
+    hip_device = -1;
 }
 
-int reserve_locked(Scratch &s, size_t bytes) {
+int Ctx::reserve(Scratch &s, size_t bytes) {
     if (bytes <= s.cap) return FR_OK;
     if (s.ptr) {
         HIP_TRY(hipFree(s.ptr));
@@ -187,8 +178,92 @@ int reserve_locked(Scratch &s, size_t bytes) {
     return FR_OK;
 }
 
+int Ctx::event(size_t k, hipEvent_t *out) {
+    while (events.size() <= k) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events.push_back(e);
+    }
+    *out = events[k];
+    return FR_OK;
+}
+
+int Ctx::acquire_palette(PaletteSlot **out) {
+    std::lock_guard<std::mutex> lk(palette_mu);
+    for (int tries = 0; tries < kPaletteSlots; tries++) {
+        PaletteSlot &s = palette_slots[palette_next++ % kPaletteSlots];
+        if (s.busy) continue; /* another thread is between acquire and its event record */
+        if (!s.dev) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * FR_MAX_PALETTE_ENTRIES));
+            HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+        if (s.pending) {
+            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if 16 renders are in flight */
+            s.pending = false;
+        }
+        s.busy = true;
+        *out = &s;
+        return FR_OK;
+    }
+    return fail(FR_ERR_HIP, "no palette slot available");
+}
+
+/* the slot may be reused once everything enqueued so far on `stream` has run */
+void Ctx::release_palette(PaletteSlot *slot, hipStream_t st) {
+    if (!slot) return;
+    const bool recorded = hipEventRecord(slot->done, st) == hipSuccess;
+    if (!recorded) (void)hipStreamSynchronize(st); /* no event to wait on later: wait now */
+    std::lock_guard<std::mutex> lk(palette_mu);
+    slot->pending = recorded;
+    slot->busy = false;
+}
+
+namespace {
+
+/* caller holds g_primary_mu */
+int init_primary_locked(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(FR_ERR_NO_DEVICE, "no HIP device available (libfractal_hip has no CPU fallback)");
+    }
+    if (device < 0) device = g_primary_inited ? g_primary.hip_device : 0;
+    if (device >= n) return fail(FR_ERR_NO_DEVICE, "device index out of range");
+    if (g_primary_inited && g_primary.hip_device == device) return FR_OK;
+    if (g_primary_inited) {
+        g_primary.destroy(); /* switching device: drop state that lives on the old one */
+        g_primary_inited = false;
+    }
+    static std::once_flag once;
+    std::call_once(once, [] { atexit([] { g_process_exiting.store(true); }); });
+    int rc = g_primary.create(device);
+    if (rc != FR_OK) {
+        g_primary.destroy();
+        return rc;
+    }
+    g_primary_inited = true;
+    return FR_OK;
+}
+
+}  // namespace
+
+/* hipSetDevice is per host thread, so every entry point re-asserts it */
+int primary(Ctx **out) {
+    {
+        std::lock_guard<std::mutex> lk(g_primary_mu);
+        if (!g_primary_inited) {
+            int rc = init_primary_locked(-1);
+            if (rc != FR_OK) return rc;
+        }
+    }
+    HIP_TRY(hipSetDevice(g_primary.hip_device));
+    *out = &g_primary;
+    return FR_OK;
+}
+
 /* calc::Config -> kernel arguments; the local grid is filled in by the caller */
-void fill_params(const fr_config *cfg, fr_kparams &p) {
+void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     memset(&p, 0, sizeof p);
     p.algo = cfg->algo;
     p.width = cfg->width;
@@ -225,15 +300,16 @@ void fill_params(const fr_config *cfg, fr_kparams &p) {
     p.block_rows = 1;
     p.y_first = 0;
     p.y_stride = 1;
-    p.refill_minrun = (uint32_t)g_refill_minrun.load();
-    p.refill_quit16 = (uint32_t)g_refill_quit16.load();
+    p.refill_minrun = (uint32_t)o.refill_minrun;
+    p.refill_quit16 = (uint32_t)o.refill_quit16;
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
-    p.cycle_shortcut = (g_cycle_shortcut.load() && cfg->iterations < (1u << 30)) ? 1u : 0u;
+    p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
+    p.colour_filter = o.colour_filter ? 1u : 0u;
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
  * (the kernels compute every coordinate themselves). */
-double host_coord(double coord, double max, double offset, double pos, double scale) {
+static double host_coord(double coord, double max, double offset, double pos, double scale) {
     return ((coord / max) - offset) / scale + pos;
 }
 
@@ -244,10 +320,10 @@ double host_coord(double coord, double max, double offset, double pos, double sc
  * using dist' <= g(dist) = 2 * (dist + Cmax)^2 * (1 + slack); T is found by inverting g M-1 times
  * from limit^2.  Falls back to the unscaled loop (0) whenever the bound is useless or any
  * parameter is outside the range the scaled form is proven for. */
-void plan_loop(const fr_config *cfg, int precision, fr_kparams &p) {
+void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p) {
     p.loop_mode = 0;
     p.skip_t = 0.0;
-    const int forced = g_loop_mode.load();
+    const int forced = o.loop_mode;
     if (forced == 0) return;
     if (cfg->algo != FR_ALGO_MANDELBROT && cfg->algo != FR_ALGO_JULIA) return;
     if (p.ncols == 0 || p.nrows == 0) return;
@@ -299,7 +375,7 @@ void plan_loop(const fr_config *cfg, int precision, fr_kparams &p) {
     }
 }
 
-int check_rows(const fr_config *cfg, uint32_t y0, uint32_t y1) {
+static int check_rows(const fr_config *cfg, uint32_t y0, uint32_t y1) {
     if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
     if (y0 > y1) return fail(FR_ERR_INVALID_ARGUMENT, "y0 > y1");
     if (y1 > cfg->height) return fail(FR_ERR_INVALID_ARGUMENT, "y1 > height");
@@ -312,36 +388,33 @@ int check_precision(int precision) {
     return FR_OK;
 }
 
-/* device-pointer render of an arbitrary local grid; no locking, no global scratch: re-entrant */
-int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_out, hipStream_t stream) {
-    plan_loop(cfg, precision, p);
+/* device-pointer render of an arbitrary local grid; no host synchronisation, no shared scratch except
+ * the palette slot `ctx` lends: re-entrant */
+int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, const Opts &o, void *d_out,
+                  hipStream_t stream) {
+    plan_loop(cfg, precision, o, p);
     /* smooth == false: the outside colour is a function of the escape index alone, so build the
-     * (iterations + 1)-entry palette once (into a library-owned slot) and let every workgroup stage it
+     * (iterations + 1)-entry palette once (into a context-owned slot) and let every workgroup stage it
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
-    if (!cfg->smooth && escape_algo && g_palette_enabled.load() && cfg->iterations < FR_MAX_PALETTE_ENTRIES &&
-        g_tile.load() <= 9) {
-        int rc = acquire_palette_slot(&slot);
+    if (!cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 10) {
+        int rc = ctx.acquire_palette(&slot);
         if (rc != FR_OK) return rc;
         p.palette = slot->dev;
         p.palette_entries = cfg->iterations + 1;
         hipError_t e = fr_launch_palette(p, slot->dev, stream);
         if (e != hipSuccess) {
-            slot->busy.store(false);
+            ctx.release_palette(slot, stream);
             return fail_hip(e, "fr_launch_palette");
         }
     }
-    /* the slot may be reused once everything enqueued so far on `stream` has run */
     struct SlotGuard {
+        Ctx &ctx;
         PaletteSlot *slot;
         hipStream_t stream;
-        ~SlotGuard() {
-            if (!slot) return;
-            slot->pending = hipEventRecord(slot->done, stream) == hipSuccess;
-            slot->busy.store(false);
-        }
-    } guard{slot, stream};
+        ~SlotGuard() { ctx.release_palette(slot, stream); }
+    } guard{ctx, slot, stream};
     fr_kout out{};
     out.rgb = static_cast<uint8_t *>(d_out);
     Profiling &pr = tl_prof;
@@ -352,21 +425,67 @@ int render_device(const fr_config *cfg, fr_kparams &p, int precision, void *d_ou
         }
         HIP_TRY(hipEventRecord(pr.e0, stream));
     }
-    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_RGB, out, g_tile.load(), stream));
+    const char *kname = "";
+    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_RGB, out, o.tile, stream, &kname));
     if (pr.enabled) {
         HIP_TRY(hipEventRecord(pr.e1, stream));
         pr.have = true;
+        pr.kernel = kname;
     }
     return FR_OK;
 }
 
-} /* namespace */
+int render_block_cyclic(Ctx &ctx, const fr_config *cfg, int precision, const Opts &o, uint32_t block_rows,
+                        uint32_t first_block, uint32_t block_stride, uint32_t max_blocks, int dest_is_image,
+                        void *d_out, size_t out_len, hipStream_t stream, uint64_t *rows_written) {
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    int rc = check_precision(precision);
+    if (rc != FR_OK) return rc;
+    if (block_rows == 0 || block_stride == 0)
+        return fail(FR_ERR_INVALID_ARGUMENT, "block_rows and block_stride must be > 0");
+    if ((uint64_t)block_rows * block_stride > 0xFFFFFFFFull)
+        return fail(FR_ERR_INVALID_ARGUMENT, "block_rows * block_stride overflows u32");
+    if (dest_is_image && block_rows % 8 != 0)
+        return fail(FR_ERR_INVALID_ARGUMENT, "in-place block-cyclic rendering needs block_rows % 8 == 0");
+    /* rows of blocks first_block, first_block + stride, ... (at most max_blocks of them; 0 = all) */
+    uint64_t rows = 0, blocks = 0;
+    for (uint64_t b = first_block; b * block_rows < cfg->height && (max_blocks == 0 || blocks < max_blocks);
+         b += block_stride, blocks++) {
+        const uint64_t left = cfg->height - b * block_rows;
+        rows += left < block_rows ? left : block_rows;
+    }
+    if (rows_written) *rows_written = rows;
+    const size_t need = dest_is_image ? (size_t)3 * cfg->width * (size_t)cfg->height : (size_t)3 * cfg->width * (size_t)rows;
+    if (rows == 0 || cfg->width == 0) return FR_OK;
+    if (!d_out) return fail(FR_ERR_INVALID_ARGUMENT, "d_out is NULL");
+    if (out_len < need)
+        return fail(FR_ERR_BUFFER_TOO_SMALL, dest_is_image ? "out_len < 3*width*height" : "out_len < 3*width*rows");
+    fr_kparams p;
+    fill_params(cfg, o, p);
+    p.nrows = (uint32_t)rows;
+    p.block_rows = block_rows;
+    p.y_first = first_block * block_rows;
+    p.y_stride = block_rows * block_stride;
+    p.out_in_place = dest_is_image ? 1u : 0u;
+    return render_device(ctx, cfg, p, precision, o, d_out, stream);
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+
 
 extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
 
-const char *fr_last_error(void) { return tl_error.c_str(); }
+#ifndef FR_BUILD_ID
+#define FR_BUILD_ID "unknown"
+#endif
+const char *fr_build_id(void) { return FR_BUILD_ID; }
+
+const char *fr_last_error(void) { return last_error().c_str(); }
 
 int fr_device_count(int *count) {
     if (!count) return fail(FR_ERR_INVALID_ARGUMENT, "count is NULL");
@@ -381,32 +500,35 @@ int fr_device_count(int *count) {
 }
 
 int fr_init(int device) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    return init_locked(device);
+    {
+        /* same device (or "keep"): nothing is torn down, so calls in flight need not be waited for */
+        LifeShared ls;
+        std::lock_guard<std::mutex> lk(g_primary_mu);
+        if (g_primary_inited && (device < 0 || device == g_primary.hip_device)) return FR_OK;
+    }
+    LifeExclusive lx; /* waits for every entry point that is using library state */
+    std::lock_guard<std::mutex> lk(g_primary_mu);
+    return init_primary_locked(device);
 }
 
 int fr_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!g.inited) return FR_OK;
-    (void)hipSetDevice(g.device);
-    if (g.stream) (void)hipStreamSynchronize(g.stream);
-    for (Scratch *s : {&g.rgb, &g.z, &g.iters, &g.misc}) {
-        if (s->ptr) (void)hipFree(s->ptr);
-        *s = Scratch();
-    }
-    release_streams_locked();
-    release_palette_slots();
-    g.inited = false;
+    LifeExclusive lx;
+    multi_shutdown_locked();
+    std::lock_guard<std::mutex> lk(g_primary_mu);
+    if (!g_primary_inited) return FR_OK;
+    g_primary.destroy();
+    g_primary_inited = false;
     return FR_OK;
 }
 
 int fr_device_name(char *buf, size_t buf_len) {
     if (!buf || buf_len == 0) return fail(FR_ERR_INVALID_ARGUMENT, "buf is NULL or empty");
-    std::lock_guard<std::mutex> lk(g.mu);
-    int rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    int rc = primary(&ctx);
     if (rc != FR_OK) return rc;
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->hip_device));
     snprintf(buf, buf_len, "%s", prop.gcnArchName);
     return FR_OK;
 }
@@ -437,10 +559,27 @@ void fr_config_new(fr_config *cfg, uint32_t algo) {
     cfg->color_weight = 0.01;
 }
 
+void fr_render_opts_init(fr_render_opts *opts) {
+    if (!opts) return;
+    const Opts o = default_opts();
+    opts->size = sizeof(fr_render_opts);
+    opts->tile = o.tile;
+    opts->loop_mode = o.loop_mode;
+    opts->palette = o.palette;
+    opts->cycle_shortcut = o.cycle_shortcut;
+    opts->refill_minrun = o.refill_minrun;
+    opts->refill_quit16 = o.refill_quit16;
+    opts->colour_filter = o.colour_filter;
+}
+
+/* ---- device-pointer renders: asynchronous, lock-free apart from the palette slot ring ---------- */
+
 static int render_rows_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
-                              size_t out_len, void *hip_stream, unsigned bytes_per_pixel) {
+                              size_t out_len, void *hip_stream, unsigned bytes_per_pixel, const fr_render_opts *opts) {
     int rc = check_rows(cfg, y0, y1);
     if (rc == FR_OK) rc = check_precision(precision);
+    Opts o;
+    if (rc == FR_OK) rc = resolve_opts(opts, o);
     if (rc != FR_OK) return rc;
     const size_t need = (size_t)bytes_per_pixel * cfg->width * (size_t)(y1 - y0);
     if (need == 0) return FR_OK;
@@ -448,44 +587,38 @@ static int render_rows_device(const fr_config *cfg, int precision, uint32_t y0, 
     if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < bytes_per_pixel*width*(y1-y0)");
     if (bytes_per_pixel == 4 && (reinterpret_cast<uintptr_t>(d_out) & 3u))
         return fail(FR_ERR_INVALID_ARGUMENT, "RGBA8 output must be 4-byte aligned");
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
+    if (rc != FR_OK) return rc;
     fr_kparams p;
-    fill_params(cfg, p);
+    fill_params(cfg, o, p);
     p.nrows = y1 - y0;
     p.y_first = y0;
     p.block_rows = p.nrows;
     p.y_stride = 0;
     p.out_rgba = bytes_per_pixel == 4 ? 1u : 0u;
-    return render_device(cfg, p, precision, d_out, static_cast<hipStream_t>(hip_stream));
+    return render_device(*ctx, cfg, p, precision, o, d_out, static_cast<hipStream_t>(hip_stream));
+}
+
+int fr_render_rows_rgb8_device_opts(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                                    size_t out_len, void *hip_stream, const fr_render_opts *opts) {
+    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 3, opts);
+}
+
+int fr_render_rows_rgba8_device_opts(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                                     size_t out_len, void *hip_stream, const fr_render_opts *opts) {
+    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 4, opts);
 }
 
 int fr_render_rows_rgb8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
                                size_t out_len, void *hip_stream) {
-    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 3);
+    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 3, nullptr);
 }
 
 int fr_render_rows_rgba8_device(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
                                 size_t out_len, void *hip_stream) {
-    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 4);
-}
-
-int fr_render_rows_rgba8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out, size_t out_len) {
-    int rc = check_rows(cfg, y0, y1);
-    if (rc == FR_OK) rc = check_precision(precision);
-    if (rc != FR_OK) return rc;
-    const size_t need = (size_t)4 * cfg->width * (size_t)(y1 - y0);
-    if (need == 0) return FR_OK;
-    if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
-    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 4*width*(y1-y0)");
-    std::lock_guard<std::mutex> lk(g.mu);
-    rc = ensure_locked();
-    if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.rgb, need);
-    if (rc != FR_OK) return rc;
-    rc = fr_render_rows_rgba8_device(cfg, precision, y0, y1, g.rgb.ptr, need, g.stream);
-    if (rc != FR_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, need, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    return FR_OK;
+    return render_rows_device(cfg, precision, y0, y1, d_out, out_len, hip_stream, 4, nullptr);
 }
 
 uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t first_block, uint32_t block_stride) {
@@ -499,48 +632,39 @@ uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t fir
     return rows;
 }
 
+int fr_render_block_cyclic_range_rgb8_device_opts(const fr_config *cfg, int precision, uint32_t block_rows,
+                                                  uint32_t first_block, uint32_t block_stride, uint32_t max_blocks,
+                                                  int dest_is_image, void *d_out, size_t out_len, void *hip_stream,
+                                                  uint64_t *rows_written, const fr_render_opts *opts) {
+    Opts o;
+    int rc = resolve_opts(opts, o);
+    if (rc != FR_OK) return rc;
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
+    if (rc != FR_OK) return rc;
+    return render_block_cyclic(*ctx, cfg, precision, o, block_rows, first_block, block_stride, max_blocks, dest_is_image,
+                               d_out, out_len, static_cast<hipStream_t>(hip_stream), rows_written);
+}
+
 int fr_render_block_cyclic_range_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
                                              uint32_t first_block, uint32_t block_stride, uint32_t max_blocks,
                                              int dest_is_image, void *d_out, size_t out_len, void *hip_stream,
                                              uint64_t *rows_written) {
-    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
-    int rc = check_precision(precision);
-    if (rc != FR_OK) return rc;
-    if (block_rows == 0 || block_stride == 0)
-        return fail(FR_ERR_INVALID_ARGUMENT, "block_rows and block_stride must be > 0");
-    if ((uint64_t)block_rows * block_stride > 0xFFFFFFFFull)
-        return fail(FR_ERR_INVALID_ARGUMENT, "block_rows * block_stride overflows u32");
-    if (dest_is_image && block_rows % 8 != 0)
-        return fail(FR_ERR_INVALID_ARGUMENT, "in-place block-cyclic rendering needs block_rows % 8 == 0");
-    /* rows of blocks first_block, first_block + stride, ... (at most max_blocks of them; 0 = all) */
-    uint64_t rows = 0, blocks = 0;
-    for (uint64_t b = first_block; b * block_rows < cfg->height && (max_blocks == 0 || blocks < max_blocks);
-         b += block_stride, blocks++) {
-        const uint64_t left = cfg->height - b * block_rows;
-        rows += left < block_rows ? left : block_rows;
-    }
-    if (rows_written) *rows_written = rows;
-    const size_t need = dest_is_image ? (size_t)3 * cfg->width * (size_t)cfg->height : (size_t)3 * cfg->width * (size_t)rows;
-    if (rows == 0 || cfg->width == 0) return FR_OK;
-    if (!d_out) return fail(FR_ERR_INVALID_ARGUMENT, "d_out is NULL");
-    if (out_len < need)
-        return fail(FR_ERR_BUFFER_TOO_SMALL, dest_is_image ? "out_len < 3*width*height" : "out_len < 3*width*rows");
-    fr_kparams p;
-    fill_params(cfg, p);
-    p.nrows = (uint32_t)rows;
-    p.block_rows = block_rows;
-    p.y_first = first_block * block_rows;
-    p.y_stride = block_rows * block_stride;
-    p.out_in_place = dest_is_image ? 1u : 0u;
-    return render_device(cfg, p, precision, d_out, static_cast<hipStream_t>(hip_stream));
+    return fr_render_block_cyclic_range_rgb8_device_opts(cfg, precision, block_rows, first_block, block_stride,
+                                                         max_blocks, dest_is_image, d_out, out_len, hip_stream,
+                                                         rows_written, nullptr);
 }
 
 int fr_render_block_cyclic_rgb8_device(const fr_config *cfg, int precision, uint32_t block_rows,
                                        uint32_t first_block, uint32_t block_stride, void *d_out, size_t out_len,
                                        void *hip_stream, uint64_t *rows_written) {
-    return fr_render_block_cyclic_range_rgb8_device(cfg, precision, block_rows, first_block, block_stride, 0, 0,
-                                                    d_out, out_len, hip_stream, rows_written);
+    return fr_render_block_cyclic_range_rgb8_device_opts(cfg, precision, block_rows, first_block, block_stride, 0, 0,
+                                                         d_out, out_len, hip_stream, rows_written, nullptr);
 }
+
+/* ---- host-buffer renders: the pipeline lives in fr_host.hip ----------------------------------- */
 
 int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t block_rows, uint32_t first_block,
                                 uint32_t block_stride, uint8_t *out, size_t out_len, uint64_t *rows_written) {
@@ -553,89 +677,38 @@ int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t bl
     if (need == 0) return check_precision(precision);
     if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
     if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*rows");
-    std::lock_guard<std::mutex> lk(g.mu);
-    int rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    int rc = primary(&ctx);
     if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.rgb, need);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    rc = ctx->reserve(ctx->rgb, need);
     if (rc != FR_OK) return rc;
-    rc = fr_render_block_cyclic_rgb8_device(cfg, precision, block_rows, first_block, block_stride, g.rgb.ptr, need,
-                                            g.stream, nullptr);
+    rc = render_block_cyclic(*ctx, cfg, precision, default_opts(), block_rows, first_block, block_stride, 0, 0,
+                             ctx->rgb.ptr, need, ctx->stream, nullptr);
     if (rc != FR_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, need, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->rgb.ptr, need, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FR_OK;
+}
+
+int fr_render_rows_rgb8_opts(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out,
+                             size_t out_len, const fr_render_opts *opts) {
+    return fr_host_render_rows(cfg, precision, y0, y1, out, out_len, 3, opts);
 }
 
 int fr_render_rows_rgb8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out,
                         size_t out_len) {
-    int rc = check_rows(cfg, y0, y1);
-    if (rc == FR_OK) rc = check_precision(precision);
-    if (rc != FR_OK) return rc;
-    const size_t row_bytes = (size_t)3 * cfg->width;
-    const size_t need = row_bytes * (size_t)(y1 - y0);
-    if (need == 0) return FR_OK;
-    if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
-    if (out_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*(y1-y0)");
-    std::lock_guard<std::mutex> lk(g.mu);
-    rc = ensure_locked();
-    if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.rgb, need);
-    if (rc != FR_OK) return rc;
-    uint8_t *scratch = static_cast<uint8_t *>(g.rgb.ptr);
-    /* Large images: pin the caller's buffer for the duration of the call and render in bands of
-     * ~64 MiB, so band k's DMA to the host (PCIe, ~57 GB/s into pinned memory) runs on the copy
-     * stream while band k+1 renders — the call costs about max(kernel, copy), not their sum.
-     * (Async copies into PAGEABLE memory are staged by the runtime and measured slower than one
-     * plain copy, so without the pin — or for small images — it is one kernel + one copy.) */
-    const bool pinned = need >= ((size_t)16 << 20) && hipHostRegister(out, need, hipHostRegisterDefault) == hipSuccess;
-    if (!pinned) {
-        (void)hipGetLastError();
-        rc = fr_render_rows_rgb8_device(cfg, precision, y0, y1, scratch, need, g.stream);
-        if (rc != FR_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(out, scratch, need, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        return FR_OK;
-    }
-    const size_t band_target = (size_t)64 << 20;
-    uint64_t bands = (need + band_target - 1) / band_target;
-    if (bands > 64) bands = 64;
-    uint64_t band_rows = ((uint64_t)(y1 - y0) + bands - 1) / bands;
-    band_rows = (band_rows + 7) / 8 * 8; /* whole 8-row tiles */
-    hipError_t err = hipSuccess;
-    const char *what = "";
-    size_t b = 0;
-    for (uint64_t ya = y0; ya < y1 && rc == FR_OK && err == hipSuccess; ya += band_rows, b++) {
-        const uint32_t yb = (uint32_t)(ya + band_rows < y1 ? ya + band_rows : y1);
-        const size_t off = row_bytes * (size_t)(ya - y0), bytes = row_bytes * (size_t)(yb - ya);
-        rc = fr_render_rows_rgb8_device(cfg, precision, (uint32_t)ya, yb, scratch + off, bytes, g.stream);
-        if (rc != FR_OK) break;
-        if (b >= g.band_done.size()) {
-            hipEvent_t e;
-            if ((err = hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) {
-                what = "hipEventCreateWithFlags";
-                break;
-            }
-            g.band_done.push_back(e);
-        }
-        if ((err = hipEventRecord(g.band_done[b], g.stream)) != hipSuccess) what = "hipEventRecord";
-        else if ((err = hipStreamWaitEvent(g.copy_stream, g.band_done[b], 0)) != hipSuccess) what = "hipStreamWaitEvent";
-        else if ((err = hipMemcpyAsync(out + off, scratch + off, bytes, hipMemcpyDeviceToHost, g.copy_stream)) != hipSuccess)
-            what = "hipMemcpyAsync";
-    }
-    /* always drain both streams and unpin before returning, error or not */
-    hipError_t e1 = hipStreamSynchronize(g.stream);
-    hipError_t e2 = hipStreamSynchronize(g.copy_stream);
-    (void)hipHostUnregister(out);
-    if (rc != FR_OK) return rc;
-    if (err != hipSuccess) return fail_hip(err, what);
-    if (e1 != hipSuccess) return fail_hip(e1, "hipStreamSynchronize(stream)");
-    if (e2 != hipSuccess) return fail_hip(e2, "hipStreamSynchronize(copy_stream)");
-    return FR_OK;
+    return fr_host_render_rows(cfg, precision, y0, y1, out, out_len, 3, nullptr);
+}
+
+int fr_render_rows_rgba8(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out, size_t out_len) {
+    return fr_host_render_rows(cfg, precision, y0, y1, out, out_len, 4, nullptr);
 }
 
 int fr_render_rgb8(const fr_config *cfg, uint8_t *out, size_t out_len) {
     if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
-    return fr_render_rows_rgb8(cfg, FR_PRECISION_F64, 0, cfg->height, out, out_len);
+    return fr_host_render_rows(cfg, FR_PRECISION_F64, 0, cfg->height, out, out_len, 3, nullptr);
 }
 
 int fr_pixel_p(const fr_config *cfg, int precision, uint32_t x, uint32_t y, fr_rgb *out) {
@@ -643,24 +716,27 @@ int fr_pixel_p(const fr_config *cfg, int precision, uint32_t x, uint32_t y, fr_r
     int rc = check_precision(precision);
     if (rc != FR_OK) return rc;
     /* get_recursive_pixel takes any u32 x, y — it does not clamp to width/height */
-    std::lock_guard<std::mutex> lk(g.mu);
-    rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
     if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.misc, 256);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    rc = ctx->reserve(ctx->misc, 256);
     if (rc != FR_OK) return rc;
+    const Opts o = default_opts();
     fr_kparams p;
-    fill_params(cfg, p);
+    fill_params(cfg, o, p);
     p.ncols = 1;
     p.nrows = 1;
     p.x_first = x;
     p.y_first = y;
-    plan_loop(cfg, precision, p);
-    fr_kout o{};
-    o.rgb = static_cast<uint8_t *>(g.misc.ptr);
-    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_RGB, o, g_tile.load(), g.stream));
+    plan_loop(cfg, precision, o, p);
+    fr_kout ko{};
+    ko.rgb = static_cast<uint8_t *>(ctx->misc.ptr);
+    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_RGB, ko, o.tile, ctx->stream, nullptr));
     uint8_t rgb[3];
-    HIP_TRY(hipMemcpyAsync(rgb, g.misc.ptr, 3, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(rgb, ctx->misc.ptr, 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     out->r = rgb[0];
     out->g = rgb[1];
     out->b = rgb[2];
@@ -677,23 +753,25 @@ int fr_recursive_batch(uint32_t iterations, const fr_imaginary *start, const fr_
     if (rc != FR_OK) return rc;
     if (n == 0) return FR_OK;
     if (!start || !c || !out_pos || !out_iters) return fail(FR_ERR_INVALID_ARGUMENT, "NULL array");
-    std::lock_guard<std::mutex> lk(g.mu);
-    rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
     if (rc != FR_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t zb = n * sizeof(fr_imaginary);
-    rc = reserve_locked(g.z, 3 * zb);
-    if (rc == FR_OK) rc = reserve_locked(g.iters, n * sizeof(uint32_t));
+    rc = ctx->reserve(ctx->z, 3 * zb);
+    if (rc == FR_OK) rc = ctx->reserve(ctx->iters, n * sizeof(uint32_t));
     if (rc != FR_OK) return rc;
-    double *d_start = static_cast<double *>(g.z.ptr);
+    double *d_start = static_cast<double *>(ctx->z.ptr);
     double *d_c = d_start + 2 * n;
     double *d_pos = d_c + 2 * n;
-    HIP_TRY(hipMemcpyAsync(d_start, start, zb, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_c, c, zb, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_start, start, zb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_c, c, zb, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(fr_launch_recursive_batch(iterations, d_start, d_c, n, limit, precision, d_pos,
-                                      static_cast<uint32_t *>(g.iters.ptr), g.stream));
-    HIP_TRY(hipMemcpyAsync(out_pos, d_pos, zb, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipMemcpyAsync(out_iters, g.iters.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+                                      static_cast<uint32_t *>(ctx->iters.ptr), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_pos, d_pos, zb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_iters, ctx->iters.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FR_OK;
 }
 
@@ -709,26 +787,29 @@ int fr_escape_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1
     if (rc != FR_OK) return rc;
     const size_t npx = (size_t)cfg->width * (size_t)(y1 - y0);
     if (npx == 0 || (!z_re_im && !iters)) return FR_OK;
-    std::lock_guard<std::mutex> lk(g.mu);
-    rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
     if (rc != FR_OK) return rc;
-    if (z_re_im) rc = reserve_locked(g.z, npx * 2 * sizeof(double));
-    if (rc == FR_OK && iters) rc = reserve_locked(g.iters, npx * sizeof(uint32_t));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (z_re_im) rc = ctx->reserve(ctx->z, npx * 2 * sizeof(double));
+    if (rc == FR_OK && iters) rc = ctx->reserve(ctx->iters, npx * sizeof(uint32_t));
     if (rc != FR_OK) return rc;
+    const Opts o = default_opts();
     fr_kparams p;
-    fill_params(cfg, p);
+    fill_params(cfg, o, p);
     p.nrows = y1 - y0;
     p.y_first = y0;
     p.block_rows = p.nrows;
     p.y_stride = 0;
-    plan_loop(cfg, precision, p);
-    fr_kout o{};
-    o.z = z_re_im ? static_cast<double *>(g.z.ptr) : nullptr;
-    o.iters = iters ? static_cast<uint32_t *>(g.iters.ptr) : nullptr;
-    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_ESCAPE, o, g_tile.load(), g.stream));
-    if (z_re_im) HIP_TRY(hipMemcpyAsync(z_re_im, g.z.ptr, npx * 2 * sizeof(double), hipMemcpyDeviceToHost, g.stream));
-    if (iters) HIP_TRY(hipMemcpyAsync(iters, g.iters.ptr, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    plan_loop(cfg, precision, o, p);
+    fr_kout ko{};
+    ko.z = z_re_im ? static_cast<double *>(ctx->z.ptr) : nullptr;
+    ko.iters = iters ? static_cast<uint32_t *>(ctx->iters.ptr) : nullptr;
+    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_ESCAPE, ko, o.tile, ctx->stream, nullptr));
+    if (z_re_im) HIP_TRY(hipMemcpyAsync(z_re_im, ctx->z.ptr, npx * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, ctx->iters.ptr, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FR_OK;
 }
 
@@ -738,21 +819,23 @@ int fr_colour_rgb8(const fr_config *cfg, const double *z_re_im, const uint32_t *
     if (n == 0) return FR_OK;
     if (!z_re_im || !iters || !out) return fail(FR_ERR_INVALID_ARGUMENT, "NULL array");
     if (out_len < 3 * n) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*n");
-    std::lock_guard<std::mutex> lk(g.mu);
-    int rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    int rc = primary(&ctx);
     if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.z, n * 2 * sizeof(double));
-    if (rc == FR_OK) rc = reserve_locked(g.iters, n * sizeof(uint32_t));
-    if (rc == FR_OK) rc = reserve_locked(g.rgb, 3 * n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    rc = ctx->reserve(ctx->z, n * 2 * sizeof(double));
+    if (rc == FR_OK) rc = ctx->reserve(ctx->iters, n * sizeof(uint32_t));
+    if (rc == FR_OK) rc = ctx->reserve(ctx->rgb, 3 * n);
     if (rc != FR_OK) return rc;
     fr_kparams p;
-    fill_params(cfg, p);
-    HIP_TRY(hipMemcpyAsync(g.z.ptr, z_re_im, n * 2 * sizeof(double), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.iters.ptr, iters, n * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(fr_launch_colour(p, static_cast<const double *>(g.z.ptr), static_cast<const uint32_t *>(g.iters.ptr), n,
-                             static_cast<uint8_t *>(g.rgb.ptr), g.stream));
-    HIP_TRY(hipMemcpyAsync(out, g.rgb.ptr, 3 * n, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    fill_params(cfg, default_opts(), p);
+    HIP_TRY(hipMemcpyAsync(ctx->z.ptr, z_re_im, n * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->iters.ptr, iters, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(fr_launch_colour(p, static_cast<const double *>(ctx->z.ptr), static_cast<const uint32_t *>(ctx->iters.ptr), n,
+                             static_cast<uint8_t *>(ctx->rgb.ptr), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->rgb.ptr, 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FR_OK;
 }
 
@@ -763,7 +846,7 @@ int fr_colour_rgb8_device(const fr_config *cfg, const void *d_z_re_im, const voi
     if (!d_z_re_im || !d_iters || !d_out) return fail(FR_ERR_INVALID_ARGUMENT, "NULL array");
     if (out_len < 3 * n) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*n");
     fr_kparams p;
-    fill_params(cfg, p);
+    fill_params(cfg, default_opts(), p);
     HIP_TRY(fr_launch_colour(p, static_cast<const double *>(d_z_re_im), static_cast<const uint32_t *>(d_iters), n,
                              static_cast<uint8_t *>(d_out), static_cast<hipStream_t>(hip_stream)));
     return FR_OK;
@@ -778,8 +861,9 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
     if (sx == 0) sx = 1;
     if (sy == 0) sy = 1;
     *total = 0;
+    const Opts o = default_opts();
     fr_kparams p;
-    fill_params(cfg, p);
+    fill_params(cfg, o, p);
     p.ncols = (uint32_t)(((uint64_t)cfg->width + sx - 1) / sx);
     p.x_stride = sx;
     const uint64_t yf = ((uint64_t)y0 + sy - 1) / sy * sy; /* first sampled row >= y0 */
@@ -789,20 +873,22 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
     p.y_stride = sy;
     if (pixels) *pixels = (uint64_t)p.ncols * p.nrows;
     if (p.ncols == 0 || p.nrows == 0) return FR_OK;
-    std::lock_guard<std::mutex> lk(g.mu);
-    rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
     if (rc != FR_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t slot_bytes = sizeof(unsigned long long) * FR_COUNT_SLOTS;
-    rc = reserve_locked(g.misc, slot_bytes);
+    rc = ctx->reserve(ctx->misc, slot_bytes);
     if (rc != FR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(g.misc.ptr, 0, slot_bytes, g.stream));
-    plan_loop(cfg, precision, p);
-    fr_kout o{};
-    o.count = static_cast<unsigned long long *>(g.misc.ptr);
-    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_COUNT, o, g_tile.load(), g.stream));
+    HIP_TRY(hipMemsetAsync(ctx->misc.ptr, 0, slot_bytes, ctx->stream));
+    plan_loop(cfg, precision, o, p);
+    fr_kout ko{};
+    ko.count = static_cast<unsigned long long *>(ctx->misc.ptr);
+    HIP_TRY(fr_launch_escape(p, precision, FR_OUT_COUNT, ko, o.tile, ctx->stream, nullptr));
     std::vector<unsigned long long> host(FR_COUNT_SLOTS);
-    HIP_TRY(hipMemcpyAsync(host.data(), g.misc.ptr, slot_bytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(host.data(), ctx->misc.ptr, slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     unsigned long long sum = 0;
     for (unsigned long long v : host) sum += v;
     *total = sum;
@@ -810,36 +896,40 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
 }
 
 int fr_set_profiling(int enabled) {
-    tl_prof.enabled = enabled != 0;
-    if (!enabled) tl_prof.have = false;
+    Profiling &pr = profiling();
+    pr.enabled = enabled != 0;
+    if (!enabled) {
+        pr.have = false;
+        if (pr.e0) { /* give the events back: a thread that stops profiling holds nothing */
+            (void)hipEventDestroy(pr.e0);
+            (void)hipEventDestroy(pr.e1);
+            pr.e0 = pr.e1 = nullptr;
+        }
+    }
     return FR_OK;
 }
 
 int fr_last_kernel_ms(float *ms) {
     if (!ms) return fail(FR_ERR_INVALID_ARGUMENT, "ms is NULL");
-    if (!tl_prof.have) return fail(FR_ERR_INVALID_ARGUMENT, "no profiled kernel on this thread");
-    HIP_TRY(hipEventSynchronize(tl_prof.e1));
-    HIP_TRY(hipEventElapsedTime(ms, tl_prof.e0, tl_prof.e1));
+    Profiling &pr = profiling();
+    if (!pr.have) return fail(FR_ERR_INVALID_ARGUMENT, "no profiled kernel on this thread");
+    HIP_TRY(hipEventSynchronize(pr.e1));
+    HIP_TRY(hipEventElapsedTime(ms, pr.e0, pr.e1));
+    return FR_OK;
+}
+
+int fr_last_kernel_name(char *buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return fail(FR_ERR_INVALID_ARGUMENT, "buf is NULL or empty");
+    Profiling &pr = profiling();
+    if (!pr.have) return fail(FR_ERR_INVALID_ARGUMENT, "no profiled kernel on this thread");
+    snprintf(buf, buf_len, "%s", pr.kernel);
     return FR_OK;
 }
 
 int fr_set_tile(int tile) {
-    switch (tile) {
-    case 0:
-    case 1:
-    case 2:
-    case 4:
-    case 8:
-    case 9:
-    case 6401:
-    case 3202:
-    case 1604:
-    case 808:
-        g_tile.store(tile);
-        return FR_OK;
-    default:
-        return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 6401, 3202, 1604 or 808");
-    }
+    if (!valid_tile(tile)) return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 10, 6401, 3202, 1604 or 808");
+    g_tile.store(tile);
+    return FR_OK;
 }
 
 int fr_set_refill_policy(int minrun, int quit16) {
@@ -859,6 +949,11 @@ int fr_set_palette(int enabled) {
     return FR_OK;
 }
 
+int fr_set_colour_filter(int enabled) {
+    g_colour_filter.store(enabled ? 1 : 0);
+    return FR_OK;
+}
+
 int fr_set_loop_mode(int mode) {
     if (mode != -1 && mode != 0 && mode != 2 && mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "loop mode must be -1 (auto), 0, 2 or 4");
@@ -866,21 +961,23 @@ int fr_set_loop_mode(int mode) {
     return FR_OK;
 }
 
-/* test hook (not part of the reference surface): elementwise device log2 (which=0), sqrt (1) or
- * x[k]/x[k+1] (2) over host arrays, so tests can compare device arithmetic with the host's. */
+/* test hook (not part of the reference surface): elementwise device arithmetic over host arrays, so
+ * tests can compare the device's roundings with the host's (see include/fractal_hip.h). */
 int fr_debug_math(int which, const double *in, double *out, size_t n) {
     if (n == 0) return FR_OK;
     if (!in || !out) return fail(FR_ERR_INVALID_ARGUMENT, "NULL array");
-    std::lock_guard<std::mutex> lk(g.mu);
-    int rc = ensure_locked();
+    LifeShared ls;
+    Ctx *ctx;
+    int rc = primary(&ctx);
     if (rc != FR_OK) return rc;
-    rc = reserve_locked(g.z, 2 * n * sizeof(double));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    rc = ctx->reserve(ctx->z, 2 * n * sizeof(double));
     if (rc != FR_OK) return rc;
-    double *d_in = static_cast<double *>(g.z.ptr), *d_out = d_in + n;
-    HIP_TRY(hipMemcpyAsync(d_in, in, n * sizeof(double), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(fr_launch_math_probe(which, d_in, d_out, n, g.stream));
-    HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    double *d_in = static_cast<double *>(ctx->z.ptr), *d_out = d_in + n;
+    HIP_TRY(hipMemcpyAsync(d_in, in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(fr_launch_math_probe(which, d_in, d_out, n, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FR_OK;
 }
 

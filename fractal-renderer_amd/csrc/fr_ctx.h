@@ -1,0 +1,162 @@
+/*
+ * fr_ctx.h — internal (C++) state shared by the translation units of the C ABI:
+ *   fr_api.hip    the single-device entry points (get_image / get_recursive_pixel / recursive)
+ *   fr_host.hip   getting a finished image from HBM into the caller's Vec<RGB>-shaped host buffer
+ *   fr_multi.hip  get_image across a set of devices from ONE process (src/lib.rs:253 has one caller)
+ * Not installed; the public boundary is include/fractal_hip.h.
+ */
+#ifndef FR_CTX_H
+#define FR_CTX_H
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fractal_hip.h"
+#include "fr_kernels.h"
+
+namespace fr {
+
+/* ---- errors: code + thread-local message (fr_last_error) ----------------------------------- */
+int fail(int code, const char *what);
+int fail(int code, const std::string &what);
+int fail_hip(hipError_t e, const char *what);
+const std::string &last_error();
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return ::fr::fail_hip(e_, #expr); \
+    } while (0)
+
+/* ---- implementation selectors of one render (fr_render_opts resolved against the defaults) --- */
+struct Opts {
+    int tile = 0;
+    int loop_mode = -1;
+    int palette = 1;
+    int cycle_shortcut = 0;
+    int refill_minrun = 32, refill_quit16 = 8;
+    int colour_filter = 1;
+};
+Opts default_opts();                             /* what the fr_set_* calls have set */
+int resolve_opts(const fr_render_opts *o, Opts &out); /* NULL = defaults; validates */
+
+/* ---- one logical device: a HIP device + the library's streams and scratch on it -------------- */
+struct Scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+/* Palette scratch for smooth == false renders: a small ring of device buffers owned by the context
+ * (no allocation on the render path, usable from any stream of that device).  A slot is handed out
+ * only after the event recorded behind its last user has completed. */
+struct PaletteSlot {
+    uint32_t *dev = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false; /* `done` was recorded and not yet waited for */
+    bool busy = false;    /* a thread is between acquire and its event record */
+};
+constexpr int kPaletteSlots = 16;
+
+struct Ctx {
+    int hip_device = -1;
+    std::mutex mu; /* serialises the host-buffer entry points (they share streams + scratch) */
+    hipStream_t stream = nullptr;      /* kernels of the host-buffer entry points */
+    hipStream_t stream2 = nullptr;     /* multi-device: chunk kernels alternate between stream / stream2 */
+    hipStream_t copy_stream = nullptr; /* D2H / peer copies, overlapped with the next band's kernel */
+    std::vector<hipEvent_t> events;
+    Scratch rgb, z, iters, misc;
+    PaletteSlot palette_slots[kPaletteSlots];
+    std::mutex palette_mu;
+    unsigned palette_next = 0;
+
+    int create(int device); /* hipSetDevice + streams; the calling thread stays on `device` */
+    void destroy();         /* frees everything (caller made sure nothing is in flight) */
+    int reserve(Scratch &s, size_t bytes);
+    int event(size_t k, hipEvent_t *out); /* k-th reusable event (created on demand) */
+    int acquire_palette(PaletteSlot **out);
+    void release_palette(PaletteSlot *slot, hipStream_t stream); /* record + make reusable */
+};
+
+/* calc::Config -> kernel arguments (the local grid is filled in by the caller) and the loop plan */
+void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p);
+void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p);
+
+/* device-pointer render of the local grid set in `p`; `ctx` lends the palette slot (it must live
+ * on the device `stream` belongs to).  No host synchronisation. */
+int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, const Opts &o, void *d_out,
+                  hipStream_t stream);
+
+/* row-block-cyclic chunk: blocks first_block, first_block + stride, ... (at most max_blocks; 0 = all) */
+int render_block_cyclic(Ctx &ctx, const fr_config *cfg, int precision, const Opts &o, uint32_t block_rows,
+                        uint32_t first_block, uint32_t block_stride, uint32_t max_blocks, int dest_is_image,
+                        void *d_out, size_t out_len, hipStream_t stream, uint64_t *rows_written);
+
+int check_precision(int precision);
+
+/* the primary context (what fr_init selected); locks and lazily creates it.  Callers hold
+ * `life_shared()` while they use it. */
+int primary(Ctx **out);
+
+/* Lifetime lock: entry points that enqueue on library state hold it shared; fr_init (device switch),
+ * fr_init_devices and fr_shutdown hold it exclusively, so state is never torn down under a call. */
+struct LifeShared {
+    LifeShared();
+    ~LifeShared();
+};
+struct LifeExclusive {
+    LifeExclusive();
+    ~LifeExclusive();
+};
+
+/* ---- host buffers (fr_host.hip) ------------------------------------------------------------- */
+
+/* Walks a host buffer in page-aligned chunks of 64 MiB, making each DMA-able in turn: where the pages
+ * do not exist yet (a fresh Vec) a background thread faults them in ahead of the walk (huge-page hint,
+ * several threads), then the chunk is pinned with hipHostRegister.  `portable` = for every device. */
+class ChunkPinner {
+  public:
+    ChunkPinner(uint8_t *out, size_t need, bool portable);
+    ~ChunkPinner();
+    /* pins the next chunk: bytes [a, b) of the buffer; pinned = false: could not be pinned (plain copy).
+     * Returns false when the walk is over. */
+    bool next(size_t &a, size_t &b, bool &pinned);
+    void release(); /* unpin everything (the caller drained its streams first) */
+    double t_touch = 0.0, t_reg = 0.0; /* ms spent waiting for the toucher / in hipHostRegister */
+
+  private:
+    uint8_t *out_;
+    size_t need_, pos_ = 0;
+    unsigned flags_;
+    std::atomic<size_t> touched_{0};
+    std::thread toucher_;
+    std::vector<uint8_t *> regs_;
+};
+void prefault(void *ptr, size_t len);
+
+/* per-thread kernel timing (fr_set_profiling / fr_last_kernel_ms) */
+struct Profiling {
+    bool enabled = false;
+    bool have = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char *kernel = "";
+    ~Profiling();
+};
+Profiling &profiling();
+
+/* multi-device teardown hook, called by fr_shutdown / fr_init_devices with the exclusive lock held */
+void multi_shutdown_locked();
+
+}  // namespace fr
+
+/* shared body of the host-buffer row renders (fr_host.hip) */
+int fr_host_render_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out, size_t out_len,
+                        unsigned bytes_per_pixel, const fr_render_opts *opts);
+
+#endif

@@ -1,0 +1,285 @@
+/*
+ * fr_host.hip — from HBM into the caller's Vec<RGB>-shaped HOST buffer (src/lib.rs:253-270: get_image
+ * returns a freshly allocated Vec every call, src/lib.rs:266-267).
+ *
+ * What the pieces cost on an MI355X box (tools/ubench/host_path.hip, 805 MB = one 16384^2 image):
+ *   D2H into pinned memory                        14.1 ms (57 GB/s, the PCIe link)
+ *   hipHostRegister of a never-touched buffer     55-77 ms (the driver faults every 4-KiB page in, serially)
+ *   first touch by T threads, 4-KiB pages         ~55 ms whatever T is (the faults serialise on the mm lock)
+ *   first touch by 8 / 16 threads after madvise(MADV_HUGEPAGE)   4.4 / 3.0 ms
+ *   hipHostRegister of touched memory             ~0.9 ms per 64 MiB;  hipHostUnregister ~0.02 ms
+ *   a pinned staging ring + memcpy threads        16-19 ms resident, 57-78 ms fresh: worse on both counts
+ * So: the image is rendered band by band into device scratch (all kernels are enqueued up front), and
+ * the caller's buffer is walked in page-aligned chunks of 64 MiB — huge-page hint + parallel first
+ * touch where the pages do not exist yet, pin, DMA behind the band that completes the chunk — so that
+ * faulting, pinning, rendering and copying all overlap and the call costs about what the slowest of
+ * them does.  Copies go straight to their final place: no staging, no second pass over the bytes.
+ */
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "fr_ctx.h"
+
+#ifndef MADV_HUGEPAGE
+#define MADV_HUGEPAGE 14
+#endif
+
+namespace fr {
+
+namespace {
+
+constexpr size_t kPage = 4096;
+constexpr size_t kHuge = (size_t)2 << 20;
+constexpr size_t kChunk = (size_t)64 << 20;
+constexpr size_t kPinThreshold = (size_t)16 << 20; /* below: one kernel + one plain copy */
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+bool trace_enabled() {
+    static const bool on = getenv("FR_TRACE") != nullptr;
+    return on;
+}
+
+int touch_threads() {
+    static const int n = [] {
+        const char *e = getenv("FR_TOUCH_THREADS");
+        if (e && atoi(e) > 0) return atoi(e) > 64 ? 64 : atoi(e);
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        return (int)(cpus >= 16 ? 8 : cpus >= 4 ? cpus / 2 : 1);
+    }();
+    return n;
+}
+
+/* are (a sample of) the pages of [p, p+len) resident?  One mincore call; unknown = "yes". */
+bool looks_resident(uint8_t *p, size_t len) {
+    uint8_t *a = reinterpret_cast<uint8_t *>(reinterpret_cast<uintptr_t>(p) & ~(kPage - 1));
+    const size_t span = (size_t)(p + len - a);
+    const size_t pages = (span + kPage - 1) / kPage;
+    std::vector<unsigned char> vec(pages);
+    if (mincore(a, span, vec.data()) != 0) return true;
+    size_t missing = 0;
+    for (size_t k = 0; k < pages; k++) missing += !(vec[k] & 1);
+    return missing * 16 < pages; /* a few swapped-out pages are not worth the threads */
+}
+
+/* Write-fault every page of [p, p+len) without changing a byte (volatile read, same value back). */
+void touch_range(uint8_t *p, size_t len) {
+    volatile uint8_t *v = p;
+    for (size_t k = 0; k < len; k += kPage) v[k] = v[k];
+    if (len) v[len - 1] = v[len - 1];
+}
+
+}  // namespace
+
+/* First touch of a fresh buffer: ask for huge pages (2 MiB: 512x fewer faults, and the kernel zeroes
+ * them outside the contended lock), then fault the range in from several threads. */
+void prefault(void *ptr, size_t len) {
+    uint8_t *p = static_cast<uint8_t *>(ptr);
+    uint8_t *ha = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(p) + kHuge - 1) & ~(kHuge - 1));
+    uint8_t *hb = reinterpret_cast<uint8_t *>(reinterpret_cast<uintptr_t>(p + len) & ~(kHuge - 1));
+    if (hb > ha) (void)madvise(ha, (size_t)(hb - ha), MADV_HUGEPAGE); /* a hint; failure is fine */
+    const int T = touch_threads();
+    if (T <= 1 || len < 8 * kHuge) {
+        touch_range(p, len);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    const size_t piece = 4 * kHuge;
+    auto work = [&] {
+        for (;;) {
+            const size_t a = next.fetch_add(piece);
+            if (a >= len) break;
+            touch_range(p + a, a + piece < len ? piece : len - a);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+/* ---- ChunkPinner: walk a host buffer in page-aligned chunks, faulting (background) and pinning ---- */
+
+ChunkPinner::ChunkPinner(uint8_t *out, size_t need, bool portable)
+    : out_(out), need_(need), flags_(portable ? hipHostRegisterPortable : hipHostRegisterDefault) {
+    const bool fresh = !looks_resident(out, need < 4 * kChunk ? need : 4 * kChunk);
+    touched_.store(fresh ? 0 : need);
+    if (fresh) {
+        /* the toucher runs ahead of the pinning loop; bytes [0, touched_) are faulted in */
+        toucher_ = std::thread([this] {
+            for (size_t a = 0; a < need_; a += kChunk) {
+                const size_t b = a + kChunk < need_ ? a + kChunk : need_;
+                prefault(out_ + a, b - a);
+                touched_.store(b, std::memory_order_release);
+            }
+        });
+    }
+}
+
+bool ChunkPinner::next(size_t &a, size_t &b, bool &pinned) {
+    if (pos_ >= need_) return false;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out_);
+    a = pos_;
+    /* chunk boundaries are page boundaries of the HOST address, so neighbouring pins never share a page */
+    b = a + kChunk;
+    if (b >= need_) b = need_;
+    else b -= (base + b) & (kPage - 1);
+    const double t0 = now_ms();
+    while (touched_.load(std::memory_order_acquire) < b) std::this_thread::yield();
+    const double t1 = now_ms();
+    uint8_t *ra = reinterpret_cast<uint8_t *>((base + a) & ~(kPage - 1));
+    uint8_t *rb = b < need_ ? out_ + b : reinterpret_cast<uint8_t *>((base + b + kPage - 1) & ~(kPage - 1));
+    const hipError_t re = hipHostRegister(ra, (size_t)(rb - ra), flags_);
+    pinned = re == hipSuccess;
+    if (pinned) {
+        regs_.push_back(ra);
+    } else {
+        (void)hipGetLastError();
+        pinned = re == hipErrorHostMemoryAlreadyRegistered; /* the caller pinned it: even better */
+    }
+    t_touch += t1 - t0;
+    t_reg += now_ms() - t1;
+    pos_ = b;
+    return true;
+}
+
+void ChunkPinner::release() {
+    if (toucher_.joinable()) toucher_.join();
+    for (uint8_t *r : regs_) (void)hipHostUnregister(r);
+    regs_.clear();
+}
+
+ChunkPinner::~ChunkPinner() { release(); }
+
+/* ---- rows [y0, y1) into a host buffer ----------------------------------------------------------- */
+
+int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &o, uint32_t y0, uint32_t y1,
+                     uint8_t *out, unsigned bpp) {
+    const size_t row_bytes = (size_t)bpp * cfg->width;
+    const size_t need = row_bytes * (size_t)(y1 - y0);
+    int rc = ctx.reserve(ctx.rgb, need);
+    if (rc != FR_OK) return rc;
+    uint8_t *scratch = static_cast<uint8_t *>(ctx.rgb.ptr);
+    const bool trace = trace_enabled();
+    const double t_start = now_ms();
+
+    auto render = [&](uint32_t ya, uint32_t yb, uint8_t *dst) -> int {
+        fr_kparams p;
+        fill_params(cfg, o, p);
+        p.nrows = yb - ya;
+        p.y_first = ya;
+        p.block_rows = p.nrows;
+        p.y_stride = 0;
+        p.out_rgba = bpp == 4 ? 1u : 0u;
+        return render_device(ctx, cfg, p, precision, o, dst, ctx.stream);
+    };
+
+    if (need < kPinThreshold) {
+        /* small image (GUI frames): one kernel, one copy; the runtime's own staging is the fastest here */
+        rc = render(y0, y1, scratch);
+        if (rc != FR_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(out, scratch, need, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        return FR_OK;
+    }
+
+    /* 1. every band's kernel, enqueued up front: the GPU renders while the host prepares the buffer */
+    uint64_t bands = (need + kChunk - 1) / kChunk;
+    if (bands > 64) bands = 64;
+    uint64_t band_rows = ((uint64_t)(y1 - y0) + bands - 1) / bands;
+    band_rows = (band_rows + 7) / 8 * 8; /* whole 8-row tiles */
+    std::vector<size_t> band_end;        /* byte offset where band k ends */
+    hipError_t err = hipSuccess;
+    const char *what = "";
+    for (uint64_t ya = y0; ya < y1 && rc == FR_OK; ya += band_rows) {
+        const uint32_t yb = (uint32_t)(ya + band_rows < y1 ? ya + band_rows : y1);
+        rc = render((uint32_t)ya, yb, scratch + row_bytes * (size_t)(ya - y0));
+        if (rc != FR_OK) break;
+        hipEvent_t e;
+        rc = ctx.event(band_end.size(), &e);
+        if (rc != FR_OK) break;
+        if ((err = hipEventRecord(e, ctx.stream)) != hipSuccess) {
+            what = "hipEventRecord";
+            break;
+        }
+        band_end.push_back(row_bytes * (size_t)(yb - y0));
+    }
+    const double t_launched = now_ms();
+
+    /* 2. the caller's buffer chunk by chunk: pin, then DMA behind the band that completes the chunk */
+    ChunkPinner pinner(out, need, false);
+    if (rc == FR_OK && err == hipSuccess) {
+        size_t a, b, band = 0;
+        bool pinned;
+        while (err == hipSuccess && pinner.next(a, b, pinned)) {
+            while (band + 1 < band_end.size() && band_end[band] < b) band++;
+            hipEvent_t e;
+            rc = ctx.event(band, &e); /* recorded above */
+            if (rc != FR_OK) break;
+            if (pinned) {
+                if ((err = hipStreamWaitEvent(ctx.copy_stream, e, 0)) != hipSuccess) what = "hipStreamWaitEvent";
+                else if ((err = hipMemcpyAsync(out + a, scratch + a, b - a, hipMemcpyDeviceToHost, ctx.copy_stream)) != hipSuccess)
+                    what = "hipMemcpyAsync";
+            } else {
+                /* memory that cannot be pinned: a plain (staged) copy once its bands are done */
+                if ((err = hipEventSynchronize(e)) != hipSuccess) what = "hipEventSynchronize";
+                else if ((err = hipMemcpy(out + a, scratch + a, b - a, hipMemcpyDeviceToHost)) != hipSuccess) what = "hipMemcpy";
+            }
+        }
+    }
+    const double t_enqueued = now_ms();
+    /* always drain both streams and unpin before returning, error or not */
+    hipError_t e1 = hipStreamSynchronize(ctx.stream);
+    hipError_t e2 = hipStreamSynchronize(ctx.copy_stream);
+    const double t_synced = now_ms();
+    pinner.release();
+    if (trace)
+        fprintf(stderr,
+                "[fr_host] %zu bytes: kernels enqueued at %.2f ms, waited for first touch %.2f, pinning %.2f, copies "
+                "enqueued at %.2f, drained at %.2f, unpinned at %.2f\n",
+                need, t_launched - t_start, pinner.t_touch, pinner.t_reg, t_enqueued - t_start, t_synced - t_start,
+                now_ms() - t_start);
+    if (rc != FR_OK) return rc;
+    if (err != hipSuccess) return fail_hip(err, what);
+    if (e1 != hipSuccess) return fail_hip(e1, "hipStreamSynchronize(stream)");
+    if (e2 != hipSuccess) return fail_hip(e2, "hipStreamSynchronize(copy_stream)");
+    return FR_OK;
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+/* Shared body of fr_render_rgb8 / fr_render_rows_rgb8(_opts) / fr_render_rows_rgba8. */
+int fr_host_render_rows(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out, size_t out_len,
+                        unsigned bpp, const fr_render_opts *opts) {
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    if (y0 > y1) return fail(FR_ERR_INVALID_ARGUMENT, "y0 > y1");
+    if (y1 > cfg->height) return fail(FR_ERR_INVALID_ARGUMENT, "y1 > height");
+    int rc = check_precision(precision);
+    Opts o;
+    if (rc == FR_OK) rc = resolve_opts(opts, o);
+    if (rc != FR_OK) return rc;
+    const size_t need = (size_t)bpp * cfg->width * (size_t)(y1 - y0);
+    if (need == 0) return FR_OK;
+    if (!out) return fail(FR_ERR_INVALID_ARGUMENT, "out is NULL");
+    if (out_len < need)
+        return fail(FR_ERR_BUFFER_TOO_SMALL, bpp == 4 ? "out_len < 4*width*(y1-y0)" : "out_len < 3*width*(y1-y0)");
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
+    if (rc != FR_OK) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return host_render_rows(*ctx, cfg, precision, o, y0, y1, out, bpp);
+}

@@ -53,6 +53,9 @@ struct fr_kparams {
     /* exact periodicity shortcut (refilling kernel, scaled loops): an orbit found bitwise back at an
      * earlier state is fast-forwarded to the cap instead of being iterated there; 0 = off */
     uint32_t cycle_shortcut;
+    /* smooth colouring: bracket log2(log2(sqrt(dist))/2) with the hardware f32 log first and take the
+     * f64 software log2 only for pixels whose bracket straddles a byte boundary; 0 = always f64 */
+    uint32_t colour_filter;
 };
 
 enum fr_out_mode {
@@ -71,9 +74,10 @@ struct fr_kout {
     unsigned long long *count;
 };
 
-/* tile = lanes_x*100 + lanes_y of the per-wave footprint; 0 = default */
+/* tile = kernel-variant selector (see fr_set_tile in include/fractal_hip.h); 0 = default.
+ * *kernel_name (may be NULL) receives a static string naming the kernel that was launched. */
 hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
-                            hipStream_t stream);
+                            hipStream_t stream, const char **kernel_name);
 
 /* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
  * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */

@@ -1042,17 +1042,24 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
     return hipGetLastError();
 }
 
+#define FR_KNAME(base, k) (sizeof(T) == 8 ? base "<double, " k ">" : base "<float, " k ">")
+
 template <typename T>
-hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream) {
-    if (p.out_in_place && tile > 9) tile = 0; /* only the strip kernels know in-place addressing */
+hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream,
+                            const char *&name) {
+    if (p.out_in_place && tile > 10) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
+        name = FR_KNAME("escape_kernel", "64x1");
         return launch_tile<T, 64, 1, 1, 4>(p, mode, out, stream);
     case 3202:
+        name = FR_KNAME("escape_kernel", "32x2");
         return launch_tile<T, 32, 2, 2, 2>(p, mode, out, stream);
     case 1604:
+        name = FR_KNAME("escape_kernel", "16x4");
         return launch_tile<T, 16, 4, 2, 2>(p, mode, out, stream);
     case 808:
+        name = FR_KNAME("escape_kernel", "8x8");
         return launch_tile<T, 8, 8, 2, 2>(p, mode, out, stream);
     case 0: {
         /* strip length by image size: long strips amortise the per-workgroup setup, short ones
@@ -1062,23 +1069,43 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
-            if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) return launch_refill<T, 7>(p, mode, out, stream);
+            if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) {
+                name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
+                return launch_refill<T, 7>(p, mode, out, stream);
+            }
+            name = FR_KNAME("escape_strip_kernel", "7 tiles");
             return launch_strips<T, 7>(p, mode, out, stream);
         }
-        if (tiles >= 65536) return launch_strips<T, 4>(p, mode, out, stream);
-        if (tiles >= 16384) return launch_strips<T, 2>(p, mode, out, stream);
+        if (tiles >= 65536) {
+            name = FR_KNAME("escape_strip_kernel", "4 tiles");
+            return launch_strips<T, 4>(p, mode, out, stream);
+        }
+        if (tiles >= 16384) {
+            name = FR_KNAME("escape_strip_kernel", "2 tiles");
+            return launch_strips<T, 2>(p, mode, out, stream);
+        }
+        name = FR_KNAME("escape_strip_kernel", "1 tile");
         return launch_strips<T, 1>(p, mode, out, stream);
     }
     case 8:
+        name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
+    case 10: /* TODO queue kernel */
     case 9: /* refilling strips; only the escape-time algorithms have orbits to refill */
-        if (p.algo != 0 && p.algo != 2) return launch_strips<T, 7>(p, mode, out, stream);
+        if (p.algo != 0 && p.algo != 2) {
+            name = FR_KNAME("escape_strip_kernel", "7 tiles");
+            return launch_strips<T, 7>(p, mode, out, stream);
+        }
+        name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
         return launch_refill<T, 7>(p, mode, out, stream);
     case 1:
+        name = FR_KNAME("escape_strip_kernel", "1 tile");
         return launch_strips<T, 1>(p, mode, out, stream);
     case 2:
+        name = FR_KNAME("escape_strip_kernel", "2 tiles");
         return launch_strips<T, 2>(p, mode, out, stream);
     case 4:
+        name = FR_KNAME("escape_strip_kernel", "4 tiles");
         return launch_strips<T, 4>(p, mode, out, stream);
     default:
         return hipErrorInvalidValue;
@@ -1156,9 +1183,12 @@ __global__ __launch_bounds__(256) void math_probe_kernel(int which, const double
 } /* namespace */
 
 hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
-                            hipStream_t stream) {
-    if (precision == 1) return launch_precision<float>(p, mode, out, tile, stream);
-    return launch_precision<double>(p, mode, out, tile, stream);
+                            hipStream_t stream, const char **kernel_name) {
+    const char *name = "";
+    const hipError_t e = precision == 1 ? launch_precision<float>(p, mode, out, tile, stream, name)
+                                        : launch_precision<double>(p, mode, out, tile, stream, name);
+    if (kernel_name) *kernel_name = name;
+    return e;
 }
 
 hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, const double *c, size_t n,

@@ -1,0 +1,581 @@
+/*
+ * fr_multi.hip — get_image across a set of devices from ONE process.
+ *
+ * The reference is one process calling get_image(&Config) once (src/main.rs:16, src/lib.rs:253) and
+ * its rayon loop spreads the rows over every core (src/lib.rs:256-258).  Here the rows are spread over
+ * every device of a set, row-block-cyclically (block b -> device b % n: the set's interior sits in
+ * the middle rows of the default view, contiguous bands would be badly unbalanced), by ONE host thread
+ * with its own streams per device.  Pixels are independent (src/lib.rs:259-264), so the only exchange is
+ * getting the finished bytes to where the caller wants them:
+ *
+ *   fr_render_rgb8_multi         the caller's HOST buffer (what get_image returns): every device DMAs
+ *                                each finished block straight to its final place over its OWN PCIe link;
+ *   fr_render_rgb8_multi_device  HBM of the set's first device: peer-to-peer DMA over xGMI, or grouped
+ *                                ncclSend / ncclRecv on a communicator from ncclCommInitAll (RCCL).
+ *
+ * A device renders several of its blocks per kernel launch ("chunk": big chunks first — launches of
+ * >= 1024 rows run at the single-launch rate — then a geometric tail 4, 2, 1 so that only one block's
+ * bytes remain to be moved when the last kernel ends), chunks alternate between two streams so that a
+ * kernel's tail overlaps the next kernel's start, and chunk c is on the wire while chunk c+1 renders.
+ */
+#include <dlfcn.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+
+#include "fr_ctx.h"
+
+namespace fr {
+
+namespace {
+
+constexpr uint32_t kDefaultBlockRows = 256;
+constexpr uint32_t kMaxChunkBlocks = 8;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+/* ---- RCCL, loaded on first use (the library itself links only the HIP runtime) ---------------- */
+
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+constexpr int kNcclUint8 = 1; /* ncclDataType_t: ncclUint8 (rccl.h) */
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<ncclComm_t> comms;
+
+    int load() {
+        if (handle) return FR_OK;
+        /* RTLD_NOLOAD first: a process that already carries RCCL (PyTorch bundles one) must not get a second */
+        for (int flags : {RTLD_NOW | RTLD_NOLOAD, RTLD_NOW}) {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                handle = dlopen(name, flags);
+                if (handle) break;
+            }
+            if (handle) break;
+        }
+        if (!handle) return fail(FR_ERR_HIP, std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"));
+        auto sym = [&](const char *n) { return dlsym(handle, n); };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+            handle = nullptr;
+            return fail(FR_ERR_HIP, "librccl lacks a required symbol");
+        }
+        return FR_OK;
+    }
+    int check(ncclResult_t r, const char *what) {
+        if (r == 0) return FR_OK;
+        return fail(FR_ERR_HIP, std::string(what) + ": " + GetErrorString(r));
+    }
+    void destroy_comms() {
+        for (ncclComm_t c : comms)
+            if (c) (void)CommDestroy(c);
+        comms.clear();
+    }
+};
+
+/* ---- one worker thread per logical device ----------------------------------------------------- */
+
+struct Worker {
+    Ctx ctx;
+    int index = 0;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, stop = false, done = false;
+    int rc = FR_OK;
+    std::string err;
+    std::vector<hipEvent_t> tev; /* timing events, two per chunk */
+
+    void loop(int device) {
+        int r = ctx.create(device);
+        finish(r);
+        for (;;) {
+            std::function<int()> t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return has_task || stop; });
+                if (stop) break;
+                t = std::move(task);
+                has_task = false;
+            }
+            finish(t());
+        }
+        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+        tev.clear();
+        ctx.destroy();
+    }
+    void finish(int r) {
+        std::lock_guard<std::mutex> lk(m);
+        rc = r;
+        err = r == FR_OK ? std::string() : last_error(); /* the worker's thread-local message */
+        done = true;
+        cv.notify_all();
+    }
+    void post(std::function<int()> t) {
+        std::lock_guard<std::mutex> lk(m);
+        task = std::move(t);
+        has_task = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+    int timing_event(size_t k, hipEvent_t *out) {
+        while (tev.size() <= k) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            tev.push_back(e);
+        }
+        *out = tev[k];
+        return FR_OK;
+    }
+};
+
+struct DeviceSet {
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<int> devices;
+    bool distinct = true;
+    std::mutex call_mu; /* one multi-device render at a time */
+    Rccl rccl;
+};
+DeviceSet *g_set = nullptr;
+thread_local fr_multi_stats tl_stats;
+
+/* Local block index ranges [j0, j1) a device renders per launch (see the file header). */
+std::vector<std::pair<uint32_t, uint32_t>> chunk_schedule(uint32_t nb) {
+    std::vector<uint32_t> sizes;
+    uint32_t rem = nb, s = 1;
+    while (rem > 0) {
+        const uint32_t t = std::min(std::min(s, rem), kMaxChunkBlocks);
+        sizes.push_back(t);
+        rem -= t;
+        s *= 2;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    uint32_t j = 0;
+    for (auto it = sizes.rbegin(); it != sizes.rend(); ++it) {
+        ranges.emplace_back(j, j + *it);
+        j += *it;
+    }
+    return ranges;
+}
+
+enum class Sink { Host, PeerCopy, Rccl };
+
+struct Job {
+    const fr_config *cfg;
+    int precision;
+    Opts opts;
+    uint32_t block_rows, nblocks, n;
+    Sink sink;
+    uint8_t *dst; /* host buffer, or the image in the first device's memory */
+    size_t dst_len;
+    int root_device;
+    /* Host sink: bytes [0, pinned_upto) of dst are DMA-able; pin_failed = use plain copies */
+    std::atomic<size_t> *pinned_upto;
+    std::atomic<bool> *pin_failed;
+    DeviceSet *set;
+};
+
+void block_range(const Job &j, uint32_t b, uint32_t &y0, uint32_t &y1) {
+    y0 = b * j.block_rows;
+    const uint64_t e = (uint64_t)y0 + j.block_rows;
+    y1 = e < j.cfg->height ? (uint32_t)e : j.cfg->height;
+}
+
+/* what device `r` of the set does for one image */
+int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
+    Ctx &ctx = w.ctx;
+    const uint32_t r = (uint32_t)w.index, n = j.n;
+    const size_t row_bytes = (size_t)3 * j.cfg->width;
+    HIP_TRY(hipSetDevice(ctx.hip_device));
+    const bool in_place = j.sink != Sink::Host && r == 0; /* the root renders straight into the image */
+    const uint64_t my_rows = fr_block_cyclic_rows(j.cfg->height, j.block_rows, r, n);
+    int rc = FR_OK;
+    if (!in_place) {
+        rc = ctx.reserve(ctx.rgb, my_rows * row_bytes);
+        if (rc != FR_OK) return rc;
+    }
+    uint8_t *scratch = static_cast<uint8_t *>(ctx.rgb.ptr);
+    const uint32_t nb_max = (j.nblocks + n - 1) / n; /* local blocks of device 0, the one with the most */
+    const auto chunks = chunk_schedule(nb_max);
+    Rccl &rc_lib = j.set->rccl;
+    ncclComm_t comm = j.sink == Sink::Rccl ? rc_lib.comms[r] : nullptr;
+    size_t local_off = 0, nkernels = 0;
+    bool plain_copies = false;
+    std::vector<std::pair<size_t, size_t>> deferred; /* (dst offset, scratch offset) of blocks to copy unpinned */
+    std::vector<size_t> deferred_len;
+
+    for (size_t c = 0; c < chunks.size() && rc == FR_OK; c++) {
+        const uint32_t j0 = chunks[c].first, j1 = chunks[c].second;
+        uint32_t first = 0, count = 0;
+        for (uint32_t k = j0; k < j1; k++) {
+            const uint64_t b = (uint64_t)k * n + r;
+            if (b < j.nblocks) {
+                if (!count) first = (uint32_t)b;
+                count++;
+            }
+        }
+        hipStream_t stream = (c & 1) ? ctx.stream2 : ctx.stream;
+        hipEvent_t done = nullptr;
+        size_t chunk_off = local_off;
+        if (count) {
+            hipEvent_t t0, t1;
+            rc = w.timing_event(2 * nkernels, &t0);
+            if (rc == FR_OK) rc = w.timing_event(2 * nkernels + 1, &t1);
+            if (rc != FR_OK) break;
+            HIP_TRY(hipEventRecord(t0, stream));
+            uint64_t rows = 0;
+            if (in_place)
+                rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, n, count, 1, j.dst, j.dst_len,
+                                         stream, &rows);
+            else
+                rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, n, count, 0,
+                                         scratch + local_off, (size_t)(my_rows * row_bytes - local_off), stream, &rows);
+            if (rc != FR_OK) break;
+            HIP_TRY(hipEventRecord(t1, stream));
+            nkernels++;
+            local_off += in_place ? 0 : rows * row_bytes;
+            rc = ctx.event(c, &done);
+            if (rc != FR_OK) break;
+            HIP_TRY(hipEventRecord(done, stream));
+        }
+        /* ---- move chunk c while chunk c+1 renders */
+        if (j.sink == Sink::Rccl) {
+            if (n == 1) continue;
+            if (r == 0) {
+                /* the root posts the receives of every peer's chunk c, per peer in the peer's sending order,
+                 * straight into the blocks' final places (they do not depend on the root's own kernels) */
+                rc = rc_lib.check(rc_lib.GroupStart(), "ncclGroupStart");
+                for (uint32_t src = 1; src < n && rc == FR_OK; src++)
+                    for (uint32_t k = j0; k < j1 && rc == FR_OK; k++) {
+                        const uint64_t b = (uint64_t)k * n + src;
+                        if (b >= j.nblocks) continue;
+                        uint32_t y0, y1;
+                        block_range(j, (uint32_t)b, y0, y1);
+                        rc = rc_lib.check(rc_lib.Recv(j.dst + row_bytes * y0, row_bytes * (y1 - y0), kNcclUint8, (int)src, comm,
+                                                      ctx.copy_stream), "ncclRecv");
+                    }
+                int rc2 = rc_lib.check(rc_lib.GroupEnd(), "ncclGroupEnd");
+                if (rc == FR_OK) rc = rc2;
+            } else if (count) {
+                HIP_TRY(hipStreamWaitEvent(ctx.copy_stream, done, 0));
+                rc = rc_lib.check(rc_lib.GroupStart(), "ncclGroupStart");
+                size_t off = chunk_off;
+                for (uint32_t k = 0; k < count && rc == FR_OK; k++) {
+                    uint32_t y0, y1;
+                    block_range(j, first + k * n, y0, y1);
+                    const size_t bytes = row_bytes * (y1 - y0);
+                    rc = rc_lib.check(rc_lib.Send(scratch + off, bytes, kNcclUint8, 0, comm, ctx.copy_stream), "ncclSend");
+                    off += bytes;
+                }
+                int rc2 = rc_lib.check(rc_lib.GroupEnd(), "ncclGroupEnd");
+                if (rc == FR_OK) rc = rc2;
+            }
+            continue;
+        }
+        if (!count || in_place) continue;
+        HIP_TRY(hipStreamWaitEvent(ctx.copy_stream, done, 0));
+        size_t off = chunk_off;
+        for (uint32_t k = 0; k < count; k++) {
+            uint32_t y0, y1;
+            block_range(j, first + k * n, y0, y1);
+            const size_t bytes = row_bytes * (y1 - y0), dst_off = row_bytes * y0;
+            if (j.sink == Sink::PeerCopy) {
+                if (ctx.hip_device == j.root_device)
+                    HIP_TRY(hipMemcpyAsync(j.dst + dst_off, scratch + off, bytes, hipMemcpyDeviceToDevice, ctx.copy_stream));
+                else
+                    HIP_TRY(hipMemcpyPeerAsync(j.dst + dst_off, j.root_device, scratch + off, ctx.hip_device, bytes,
+                                               ctx.copy_stream));
+            } else {
+                /* the main thread pins the buffer front to back while we render: wait for this block's bytes */
+                while (!plain_copies && j.pinned_upto->load(std::memory_order_acquire) < dst_off + bytes) {
+                    if (j.pin_failed->load(std::memory_order_acquire)) plain_copies = true;
+                    else std::this_thread::yield();
+                }
+                if (plain_copies) {
+                    deferred.emplace_back(dst_off, off);
+                    deferred_len.push_back(bytes);
+                } else {
+                    HIP_TRY(hipMemcpyAsync(j.dst + dst_off, scratch + off, bytes, hipMemcpyDeviceToHost, ctx.copy_stream));
+                }
+            }
+            off += bytes;
+        }
+    }
+    /* drain, error or not */
+    hipError_t e1 = hipStreamSynchronize(ctx.stream);
+    hipError_t e2 = hipStreamSynchronize(ctx.stream2);
+    hipError_t e3 = hipStreamSynchronize(ctx.copy_stream);
+    if (rc != FR_OK) return rc;
+    if (e1 != hipSuccess) return fail_hip(e1, "hipStreamSynchronize(stream)");
+    if (e2 != hipSuccess) return fail_hip(e2, "hipStreamSynchronize(stream2)");
+    if (e3 != hipSuccess) return fail_hip(e3, "hipStreamSynchronize(copy_stream)");
+    for (size_t k = 0; k < deferred.size(); k++) /* host memory that could not be pinned */
+        HIP_TRY(hipMemcpy(j.dst + deferred[k].first, scratch + deferred[k].second, deferred_len[k], hipMemcpyDeviceToHost));
+    float total = 0.0f;
+    for (size_t k = 0; k < nkernels; k++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, w.tev[2 * k], w.tev[2 * k + 1]));
+        total += ms;
+    }
+    stats->kernels[r] = (uint32_t)nkernels;
+    stats->kernel_ms[r] = total;
+    stats->rows[r] = my_rows;
+    return FR_OK;
+}
+
+int ensure_rccl(DeviceSet &set) {
+    if (!set.distinct) return fail(FR_ERR_INVALID_ARGUMENT, "FR_GATHER_RCCL needs distinct devices (a communicator cannot hold one GPU twice)");
+    int rc = set.rccl.load();
+    if (rc != FR_OK) return rc;
+    if (set.rccl.comms.empty()) {
+        set.rccl.comms.assign(set.devices.size(), nullptr);
+        rc = set.rccl.check(set.rccl.CommInitAll(set.rccl.comms.data(), (int)set.devices.size(), set.devices.data()),
+                            "ncclCommInitAll");
+        if (rc != FR_OK) set.rccl.comms.clear();
+    }
+    return rc;
+}
+
+int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sink, uint8_t *dst, size_t dst_len) {
+    if (!cfg) return fail(FR_ERR_INVALID_ARGUMENT, "cfg is NULL");
+    int rc = check_precision(precision);
+    if (rc != FR_OK) return rc;
+    if (block_rows == 0) block_rows = kDefaultBlockRows;
+    if (block_rows % 8 != 0) return fail(FR_ERR_INVALID_ARGUMENT, "block_rows must be a multiple of 8");
+    const size_t need = (size_t)3 * cfg->width * (size_t)cfg->height;
+    if (need == 0) return FR_OK;
+    if (!dst) return fail(FR_ERR_INVALID_ARGUMENT, "output buffer is NULL");
+    if (dst_len < need) return fail(FR_ERR_BUFFER_TOO_SMALL, "out_len < 3*width*height");
+    LifeShared ls;
+    DeviceSet *set = g_set;
+    if (!set) return fail(FR_ERR_INVALID_ARGUMENT, "no device set: call fr_init_devices first");
+    std::lock_guard<std::mutex> lk(set->call_mu);
+    const double t_start = now_ms();
+    const uint32_t n = (uint32_t)set->workers.size();
+    if ((uint64_t)block_rows * n > 0xFFFFFFFFull) return fail(FR_ERR_INVALID_ARGUMENT, "block_rows * devices overflows u32");
+    if (sink == Sink::Rccl) {
+        rc = ensure_rccl(*set);
+        if (rc != FR_OK) return rc;
+    }
+    std::atomic<size_t> pinned_upto{0};
+    std::atomic<bool> pin_failed{false};
+    Job job{cfg, precision, default_opts(), block_rows, (uint32_t)(((uint64_t)cfg->height + block_rows - 1) / block_rows), n, sink,
+            dst, dst_len, set->devices[0], &pinned_upto, &pin_failed, set};
+    fr_multi_stats stats;
+    memset(&stats, 0, sizeof stats);
+    stats.n_devices = n;
+    for (auto &w : set->workers) {
+        Worker *wp = w.get();
+        wp->post([wp, &job, &stats] { return device_job(*wp, job, &stats); });
+    }
+    /* Host sink: while the devices render, make the caller's buffer DMA-able front to back */
+    std::unique_ptr<ChunkPinner> pinner;
+    if (sink == Sink::Host) {
+        pinner.reset(new ChunkPinner(dst, need, true));
+        size_t a, b;
+        bool pinned;
+        while (pinner->next(a, b, pinned)) {
+            if (!pinned) {
+                pin_failed.store(true, std::memory_order_release);
+                break;
+            }
+            pinned_upto.store(b, std::memory_order_release);
+        }
+    }
+    std::string first_err;
+    for (auto &w : set->workers) {
+        const int r = w->wait();
+        if (r != FR_OK && rc == FR_OK) {
+            rc = r;
+            first_err = "device " + std::to_string(w->index) + ": " + w->err;
+        }
+    }
+    if (pinner) pinner->release();
+    stats.wall_ms = now_ms() - t_start;
+    tl_stats = stats;
+    if (rc != FR_OK) return fail(rc, first_err);
+    return FR_OK;
+}
+
+}  // namespace
+
+/* exclusive lifetime lock held by the caller */
+void multi_shutdown_locked() {
+    DeviceSet *set = g_set;
+    g_set = nullptr;
+    if (!set) return;
+    set->rccl.destroy_comms();
+    for (auto &w : set->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->stop = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    delete set;
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" {
+
+int fr_init_devices(const int *devices, int n) {
+    if (!devices || n <= 0 || n > FR_MAX_DEVICES) return fail(FR_ERR_INVALID_ARGUMENT, "need 1..16 device indices");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(FR_ERR_NO_DEVICE, "no HIP device available (libfractal_hip has no CPU fallback)");
+    }
+    for (int k = 0; k < n; k++)
+        if (devices[k] < 0 || devices[k] >= count) return fail(FR_ERR_NO_DEVICE, "device index out of range");
+    LifeExclusive lx;
+    multi_shutdown_locked();
+    std::unique_ptr<DeviceSet> set(new DeviceSet);
+    set->devices.assign(devices, devices + n);
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++)
+            if (devices[a] == devices[b]) set->distinct = false;
+    int rc = FR_OK;
+    std::string err;
+    for (int k = 0; k < n; k++) {
+        std::unique_ptr<Worker> w(new Worker);
+        w->index = k;
+        Worker *wp = w.get();
+        const int dev = devices[k];
+        wp->th = std::thread([wp, dev] { wp->loop(dev); });
+        set->workers.push_back(std::move(w));
+    }
+    for (auto &w : set->workers) {
+        const int r = w->wait(); /* context creation */
+        if (r != FR_OK && rc == FR_OK) {
+            rc = r;
+            err = w->err;
+        }
+    }
+    /* peer access from every device to the root's memory (the peer-copy gather writes there) */
+    if (rc == FR_OK) {
+        const int root = devices[0];
+        for (auto &w : set->workers) {
+            Worker *wp = w.get();
+            wp->post([wp, root] {
+                if (wp->ctx.hip_device == root) return (int)FR_OK;
+                int can = 0;
+                HIP_TRY(hipDeviceCanAccessPeer(&can, wp->ctx.hip_device, root));
+                if (!can) return (int)FR_OK; /* hipMemcpyPeerAsync then stages through the host */
+                hipError_t pe = hipDeviceEnablePeerAccess(root, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail_hip(pe, "hipDeviceEnablePeerAccess");
+                (void)hipGetLastError();
+                return (int)FR_OK;
+            });
+        }
+        for (auto &w : set->workers) {
+            const int r = w->wait();
+            if (r != FR_OK && rc == FR_OK) {
+                rc = r;
+                err = w->err;
+            }
+        }
+    }
+    g_set = set.release();
+    if (rc != FR_OK) {
+        multi_shutdown_locked();
+        return fail(rc, err);
+    }
+    return FR_OK;
+}
+
+int fr_multi_device_count(int *count) {
+    if (!count) return fail(FR_ERR_INVALID_ARGUMENT, "count is NULL");
+    LifeShared ls;
+    *count = g_set ? (int)g_set->workers.size() : 0;
+    return FR_OK;
+}
+
+int fr_render_rgb8_multi(const fr_config *cfg, int precision, uint32_t block_rows, uint8_t *out, size_t out_len) {
+    return run_multi(cfg, precision, block_rows, Sink::Host, out, out_len);
+}
+
+int fr_render_rgb8_multi_device(const fr_config *cfg, int precision, uint32_t block_rows, int gather, void *d_out,
+                                size_t out_len) {
+    if (gather != FR_GATHER_PEER_COPY && gather != FR_GATHER_RCCL)
+        return fail(FR_ERR_INVALID_ARGUMENT, "gather must be FR_GATHER_PEER_COPY or FR_GATHER_RCCL");
+    return run_multi(cfg, precision, block_rows, gather == FR_GATHER_RCCL ? Sink::Rccl : Sink::PeerCopy,
+                     static_cast<uint8_t *>(d_out), out_len);
+}
+
+int fr_multi_last_stats(fr_multi_stats *stats) {
+    if (!stats) return fail(FR_ERR_INVALID_ARGUMENT, "stats is NULL");
+    *stats = tl_stats;
+    return FR_OK;
+}
+
+int fr_debug_rccl_selftest(size_t bytes) {
+    if (bytes == 0) return FR_OK;
+    LifeShared ls;
+    DeviceSet *set = g_set;
+    if (!set) return fail(FR_ERR_INVALID_ARGUMENT, "no device set: call fr_init_devices first");
+    std::lock_guard<std::mutex> lk(set->call_mu);
+    int rc = ensure_rccl(*set);
+    if (rc != FR_OK) return rc;
+    Worker *w = set->workers[0].get();
+    Rccl *lib = &set->rccl;
+    w->post([w, lib, bytes] {
+        Ctx &ctx = w->ctx;
+        HIP_TRY(hipSetDevice(ctx.hip_device));
+        int rc = ctx.reserve(ctx.misc, 2 * bytes);
+        if (rc != FR_OK) return rc;
+        uint8_t *src = static_cast<uint8_t *>(ctx.misc.ptr), *dst = src + bytes;
+        HIP_TRY(hipMemsetAsync(src, 0xA7, bytes, ctx.copy_stream));
+        HIP_TRY(hipMemsetAsync(dst, 0, bytes, ctx.copy_stream));
+        rc = lib->check(lib->GroupStart(), "ncclGroupStart");
+        if (rc == FR_OK) rc = lib->check(lib->Recv(dst, bytes, kNcclUint8, 0, lib->comms[0], ctx.copy_stream), "ncclRecv");
+        if (rc == FR_OK) rc = lib->check(lib->Send(src, bytes, kNcclUint8, 0, lib->comms[0], ctx.copy_stream), "ncclSend");
+        int rc2 = lib->check(lib->GroupEnd(), "ncclGroupEnd");
+        if (rc == FR_OK) rc = rc2;
+        if (rc != FR_OK) return rc;
+        std::vector<uint8_t> host(bytes);
+        HIP_TRY(hipMemcpyAsync(host.data(), dst, bytes, hipMemcpyDeviceToHost, ctx.copy_stream));
+        HIP_TRY(hipStreamSynchronize(ctx.copy_stream));
+        for (uint8_t v : host)
+            if (v != 0xA7) return fail(FR_ERR_HIP, "RCCL self send/recv delivered wrong bytes");
+        return (int)FR_OK;
+    });
+    rc = w->wait();
+    if (rc != FR_OK) return fail(rc, w->err);
+    return FR_OK;
+}
+
+} /* extern "C" */

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 1
+#define FR_ABI_VERSION 2
 
 typedef enum fr_status {
     FR_OK = 0,
@@ -99,8 +99,9 @@ typedef enum fr_precision { FR_PRECISION_F64 = 0, FR_PRECISION_F32 = 1 } fr_prec
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 
-/* Select the HIP device this process renders on (-1 = keep the current one / device 0) and
- * create the library's state.  Optional: compute calls auto-initialise on device 0. */
+/* Select the HIP device the single-device entry points render on (-1 = keep the current one /
+ * device 0) and create the library's state.  Optional: compute calls auto-initialise on device 0.
+ * Switching to another device waits for every call in flight and frees the state on the old one. */
 int fr_init(int device);
 /* Release streams and scratch memory.  Safe to call twice; the library can be re-initialised. */
 int fr_shutdown(void);
@@ -109,6 +110,8 @@ int fr_device_count(int *count);
 int fr_device_name(char *buf, size_t buf_len);
 const char *fr_last_error(void);
 int fr_abi_version(void);
+/* SHA-256 prefix over the sources and flags this binary was built from (fractal-renderer_amd/build.py) */
+const char *fr_build_id(void);
 
 /* Config::new(algo) — calc/src/lib.rs:39-69 */
 void fr_config_new(fr_config *cfg, uint32_t algo);
@@ -157,6 +160,79 @@ int fr_render_block_cyclic_rgb8(const fr_config *cfg, int precision, uint32_t bl
 uint64_t fr_block_cyclic_rows(uint32_t height, uint32_t block_rows, uint32_t first_block,
                               uint32_t block_stride);
 
+/* ---- per-call implementation selectors ------------------------------------------------------- */
+
+/* Everything the fr_set_* calls below select process-wide, as an argument of ONE call, so that two
+ * threads (the GUI's render and screenshot threads, src/gui.rs:56-60, 322-326) never share a knob.
+ * None of them changes a single output byte.  Fill with fr_render_opts_init() (the process
+ * defaults), change what you need, pass to an *_opts entry point; NULL means "the defaults". */
+typedef struct fr_render_opts {
+    uint32_t size;          /* sizeof(fr_render_opts): lets the struct grow without an ABI break */
+    int32_t tile;           /* see fr_set_tile */
+    int32_t loop_mode;      /* see fr_set_loop_mode */
+    int32_t palette;        /* see fr_set_palette */
+    int32_t cycle_shortcut; /* see fr_set_cycle_shortcut */
+    int32_t refill_minrun;  /* see fr_set_refill_policy */
+    int32_t refill_quit16;
+    int32_t colour_filter;  /* see fr_set_colour_filter */
+} fr_render_opts;
+void fr_render_opts_init(fr_render_opts *opts);
+
+int fr_render_rows_rgb8_device_opts(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                                    size_t out_len, void *hip_stream, const fr_render_opts *opts);
+int fr_render_rows_rgba8_device_opts(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, void *d_out,
+                                     size_t out_len, void *hip_stream, const fr_render_opts *opts);
+int fr_render_rows_rgb8_opts(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, uint8_t *out,
+                             size_t out_len, const fr_render_opts *opts);
+int fr_render_block_cyclic_range_rgb8_device_opts(const fr_config *cfg, int precision, uint32_t block_rows,
+                                                  uint32_t first_block, uint32_t block_stride, uint32_t max_blocks,
+                                                  int dest_is_image, void *d_out, size_t out_len, void *hip_stream,
+                                                  uint64_t *rows_written, const fr_render_opts *opts);
+
+/* ---- get_image across several GPUs from ONE process ---------------------------------------- */
+
+/* The reference is one process calling get_image once (src/main.rs:16, src/lib.rs:253); its rayon
+ * loop spreads the rows over every core (src/lib.rs:256-258).  The counterpart here spreads row
+ * blocks over every device of a set: block b (block_rows rows) is rendered by device b % n — the
+ * set's interior sits in the middle rows of the default view, so contiguous bands would be badly
+ * unbalanced — by one host thread and one set of streams per device.
+ *
+ * fr_init_devices: `devices` lists HIP device indices; an index may repeat ("logical devices" that
+ * share a GPU: how a one-GPU box exercises the whole path).  Replaces any earlier set.  n <= 16. */
+int fr_init_devices(const int *devices, int n);
+int fr_multi_device_count(int *count);
+
+/* Whole image into the caller's HOST buffer (>= 3*width*height bytes): every device DMAs each of its
+ * finished row blocks straight to the block's final place over its own PCIe link while it renders
+ * the next ones.  This is what a multi-GPU get_image costs its caller.  block_rows = 0: default (256). */
+int fr_render_rgb8_multi(const fr_config *cfg, int precision, uint32_t block_rows, uint8_t *out, size_t out_len);
+
+/* Whole image gathered into DEVICE memory of the set's first device (d_out, >= 3*width*height bytes,
+ * allocated by the caller on that device): the first device renders its blocks in place, the others
+ * send each finished block to its place over xGMI while they render the next ones —
+ *   FR_GATHER_PEER_COPY  peer-to-peer DMA (hipMemcpyPeerAsync), works for repeated device indices too;
+ *   FR_GATHER_RCCL       grouped ncclSend / ncclRecv on a communicator from ncclCommInitAll
+ *                        (librccl is loaded on first use; needs distinct devices). */
+typedef enum fr_gather { FR_GATHER_PEER_COPY = 0, FR_GATHER_RCCL = 1 } fr_gather;
+int fr_render_rgb8_multi_device(const fr_config *cfg, int precision, uint32_t block_rows, int gather, void *d_out,
+                                size_t out_len);
+
+/* Timing of the calling thread's last multi-device render: per device, the time its render kernels
+ * took (HIP events, summed over its chunks) and the host-side wall time of the whole call. */
+#define FR_MAX_DEVICES 16
+typedef struct fr_multi_stats {
+    uint32_t n_devices;
+    uint32_t kernels[FR_MAX_DEVICES];   /* render kernels launched on each device */
+    float kernel_ms[FR_MAX_DEVICES];    /* their summed duration */
+    uint64_t rows[FR_MAX_DEVICES];      /* rows each device rendered */
+    double wall_ms;                     /* the call, entry to return */
+} fr_multi_stats;
+int fr_multi_last_stats(fr_multi_stats *stats);
+
+/* Test hook: one grouped self send/recv of `bytes` bytes through RCCL on the set's first device
+ * (loads librccl, creates the communicator) — the only RCCL traffic a one-GPU box can carry. */
+int fr_debug_rccl_selftest(size_t bytes);
+
 /* ---- get_recursive_pixel — calc/src/lib.rs:199-235 ---------------------------------------- */
 
 int fr_pixel(const fr_config *cfg, uint32_t x, uint32_t y, fr_rgb *out);
@@ -200,6 +276,9 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
  * duration.  State is per calling thread. */
 int fr_set_profiling(int enabled);
 int fr_last_kernel_ms(float *ms);
+/* Name of the render kernel the calling thread's last device-pointer render launched (profiling on),
+ * e.g. "escape_strip_kernel<double, RGB, 7>": bench.py reports what actually ran. */
+int fr_last_kernel_name(char *buf, size_t buf_len);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
  * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
@@ -227,6 +306,13 @@ int fr_set_cycle_shortcut(int enabled);
  * escape index, built once per call on the device) when iterations < 1280; 0 disables that and
  * computes the colour per pixel.  Same bytes either way (tests compare them). */
 int fr_set_palette(int enabled);
+
+/* Smooth colouring needs log2(log2(sqrt(dist)) / 2) per outside pixel (calc/src/lib.rs:222-223).  With
+ * the filter on (default) the kernel first brackets that value with the hardware's f32 log and a
+ * proven error bound, evaluates the rest of the colour map in f64 at both ends of the bracket and
+ * keeps the bytes if they agree (the map is monotone); only pixels whose bracket straddles a byte
+ * boundary take the full f64 software log2.  Same bytes either way (tests compare them). */
+int fr_set_colour_filter(int enabled);
 
 /* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled
  * loop with an escape check every iteration; 4 / 2 = the scaled loop that checks every 4th / 2nd
