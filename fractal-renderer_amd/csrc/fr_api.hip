@@ -47,7 +47,7 @@ bool g_primary_inited = false;
 std::atomic<int> g_tile{0};
 std::atomic<int> g_palette_enabled{1};
 std::atomic<int> g_cycle_shortcut{0};
-std::atomic<int> g_refill_minrun{32}, g_refill_quit16{8};
+std::atomic<int> g_refill_minrun{-1}, g_refill_quit16{-1}; /* -1: each kernel's own default */
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 std::atomic<int> g_colour_filter{1};
 
@@ -116,8 +116,8 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 6401, 3202, 1604 or 808");
     if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
-    if (in->refill_minrun < 0 || in->refill_quit16 < 1 || in->refill_quit16 > 16)
-        return fail(FR_ERR_INVALID_ARGUMENT, "opts: refill_minrun >= 0, 1 <= refill_quit16 <= 16");
+    if (in->refill_minrun < -1 || in->refill_quit16 < -1 || in->refill_quit16 == 0 || in->refill_quit16 > 16)
+        return fail(FR_ERR_INVALID_ARGUMENT, "opts: refill_minrun >= 0, 1 <= refill_quit16 <= 16 (or -1: the kernel's default)");
     o.tile = in->tile;
     o.loop_mode = in->loop_mode;
     o.palette = in->palette != 0;
@@ -194,7 +194,7 @@ int Ctx::acquire_palette(PaletteSlot **out) {
         PaletteSlot &s = palette_slots[palette_next++ % kPaletteSlots];
         if (s.busy) continue; /* another thread is between acquire and its event record */
         if (!s.dev) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * FR_MAX_PALETTE_ENTRIES));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * (FR_MAX_PALETTE_ENTRIES + 16)));
             HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         }
         if (s.pending) {
@@ -300,11 +300,22 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     p.block_rows = 1;
     p.y_first = 0;
     p.y_stride = 1;
-    p.refill_minrun = (uint32_t)o.refill_minrun;
-    p.refill_quit16 = (uint32_t)o.refill_quit16;
+    /* episode policies (measured defaults): the patch-refill kernel ends an episode once half of its running
+     * lanes have finished and 32 iterations were done; the work-queue kernel, whose refill is much cheaper,
+     * once 24 lanes are free and 8 iterations were done */
+    p.refill_minrun = o.refill_minrun < 0 ? 32u : (uint32_t)o.refill_minrun;
+    p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
+    p.queue_minrun = o.refill_minrun < 0 ? 8u : (uint32_t)o.refill_minrun;
+    p.queue_want = o.refill_quit16 < 0 ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
-    p.colour_filter = o.colour_filter ? 1u : 0u;
+    /* the colour filter's constants (fr_kernels.hip: colour_outside_filtered) and the conditions under
+     * which its error analysis holds: a positive cap, a finite, not absurd exposure */
+    p.filt_k = n != 0 ? cfg->exposure / (double)n : 0.0;
+    const bool filter_ok = o.colour_filter && cfg->smooth && n != 0 && std::isfinite(cfg->exposure) &&
+                           std::fabs(p.filt_k) <= 1e100 && cfg->stable_limit >= 0.0;
+    p.colour_filter = filter_ok ? 1u : 0u;
+    for (int k = 0; k < 3; k++) p.filt_d[k] = p.prim_f[k] * std::fabs(p.filt_k) * FR_NU_BRACKET * (1.0 + 0x1p-20);
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
@@ -398,9 +409,21 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
-    if (!cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 10) {
+    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 10;
+    const bool want_queue = fr_wants_work_queue(p, o.tile);
+    if (want_palette || want_queue) {
         int rc = ctx.acquire_palette(&slot);
         if (rc != FR_OK) return rc;
+    }
+    if (want_queue) { /* the persistent waves' patch counter lives behind the slot's palette words */
+        p.work_counter = slot->dev + FR_MAX_PALETTE_ENTRIES;
+        hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) {
+            ctx.release_palette(slot, stream);
+            return fail_hip(e, "hipMemsetAsync(work counter)");
+        }
+    }
+    if (want_palette) {
         p.palette = slot->dev;
         p.palette_entries = cfg->iterations + 1;
         hipError_t e = fr_launch_palette(p, slot->dev, stream);
@@ -933,7 +956,8 @@ int fr_set_tile(int tile) {
 }
 
 int fr_set_refill_policy(int minrun, int quit16) {
-    if (minrun < 0 || quit16 < 1 || quit16 > 16) return fail(FR_ERR_INVALID_ARGUMENT, "minrun >= 0, 1 <= quit16 <= 16");
+    if (minrun < -1 || quit16 < -1 || quit16 == 0 || quit16 > 16)
+        return fail(FR_ERR_INVALID_ARGUMENT, "minrun >= 0, 1 <= quit16 <= 16 (or -1: the kernel's default)");
     g_refill_minrun.store(minrun);
     g_refill_quit16.store(quit16);
     return FR_OK;
@@ -974,6 +998,13 @@ int fr_debug_math(int which, const double *in, double *out, size_t n) {
     rc = ctx->reserve(ctx->z, 2 * n * sizeof(double));
     if (rc != FR_OK) return rc;
     double *d_in = static_cast<double *>(ctx->z.ptr), *d_out = d_in + n;
+    if (which == 4) { /* colour-filter scan: in[0], in[1] = first and last f32 bit pattern; out[0] = worst error */
+        if (n < 2) return fail(FR_ERR_INVALID_ARGUMENT, "which == 4 needs n >= 2");
+        HIP_TRY(fr_launch_nu_scan((uint32_t)in[0], (uint32_t)in[1], d_out, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return FR_OK;
+    }
     HIP_TRY(hipMemcpyAsync(d_in, in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(fr_launch_math_probe(which, d_in, d_out, n, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -41,7 +41,7 @@ struct Opts {
     int loop_mode = -1;
     int palette = 1;
     int cycle_shortcut = 0;
-    int refill_minrun = 32, refill_quit16 = 8;
+    int refill_minrun = -1, refill_quit16 = -1; /* -1: each kernel's own default */
     int colour_filter = 1;
 };
 Opts default_opts();                             /* what the fr_set_* calls have set */
@@ -57,7 +57,7 @@ struct Scratch {
  * (no allocation on the render path, usable from any stream of that device).  A slot is handed out
  * only after the event recorded behind its last user has completed. */
 struct PaletteSlot {
-    uint32_t *dev = nullptr;
+    uint32_t *dev = nullptr; /* FR_MAX_PALETTE_ENTRIES palette words, then the work-queue kernel's counter */
     hipEvent_t done = nullptr;
     bool pending = false; /* `done` was recorded and not yet waited for */
     bool busy = false;    /* a thread is between acquire and its event record */
@@ -128,6 +128,9 @@ class ChunkPinner {
      * Returns false when the walk is over. */
     bool next(size_t &a, size_t &b, bool &pinned);
     void release(); /* unpin everything (the caller drained its streams first) */
+    /* where the chunk starting at byte `a` ends: a pure function of (out, need, a), so that other threads
+     * can split their copies at the same places (one DMA must not span two pins) */
+    static size_t chunk_end(const uint8_t *out, size_t need, size_t a);
     double t_touch = 0.0, t_reg = 0.0; /* ms spent waiting for the toucher / in hipHostRegister */
 
   private:

@@ -50,13 +50,24 @@ struct fr_kparams {
     /* refilling kernel: an episode may end early once `refill_quit16`/16 of its running lanes have
      * finished and `refill_minrun` iterations were done (see fr_kernels.hip) */
     uint32_t refill_minrun, refill_quit16;
+    /* work-queue kernel: while more pixels wait, an episode ends once `queue_want` lanes have finished and
+     * `queue_minrun` iterations were done */
+    uint32_t queue_minrun, queue_want;
     /* exact periodicity shortcut (refilling kernel, scaled loops): an orbit found bitwise back at an
      * earlier state is fast-forwarded to the cap instead of being iterated there; 0 = off */
     uint32_t cycle_shortcut;
     /* smooth colouring: bracket log2(log2(sqrt(dist))/2) with the hardware f32 log first and take the
      * f64 software log2 only for pixels whose bracket straddles a byte boundary; 0 = always f64 */
     uint32_t colour_filter;
+    /* work-queue kernel: a device counter, zeroed on the launch stream, from which its persistent waves
+     * draw patches; NULL = that kernel is not available to this launch */
+    uint32_t *work_counter;
+    double filt_k;    /* exposure / iterations (any rounding) */
+    double filt_d[3]; /* per stored colour field: |field * filt_k| * FR_NU_BRACKET * (1 + 2^-20) */
 };
+
+/* half-width of the colour filter's bracket around its f32 estimate of nu (fr_kernels.hip) */
+constexpr double FR_NU_BRACKET = 0x1p-18;
 
 enum fr_out_mode {
     FR_OUT_RGB = 0,    /* packed r,g,b at 3*(r*ncols + cx)                    */
@@ -79,6 +90,10 @@ struct fr_kout {
 hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
                             hipStream_t stream, const char **kernel_name);
 
+/* Would fr_launch_escape(p, ..., FR_OUT_RGB, ..., tile) pick the work-queue kernel if p.work_counter were set?
+ * (The caller then lends a counter and zeroes it on the launch stream.) */
+bool fr_wants_work_queue(const fr_kparams &p, int tile);
+
 /* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
  * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */
 constexpr uint32_t FR_MAX_PALETTE_ENTRIES = 1280;
@@ -98,5 +113,8 @@ hipError_t fr_launch_recursive_batch(uint32_t iterations, const double *start, c
 
 /* test hooks: elementwise device log2 / sqrt over n doubles */
 hipError_t fr_launch_math_probe(int which, const double *in, double *out, size_t n, hipStream_t stream);
+
+/* test hook: largest |filter bracket centre - f64 nu| over every f32 bit pattern in [lo, hi] -> out[0] (device) */
+hipError_t fr_launch_nu_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hipStream_t stream);
 
 #endif

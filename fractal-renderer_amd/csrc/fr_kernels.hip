@@ -43,6 +43,9 @@ struct ColourConsts {
     double inv_iterations; /* exact reciprocal when iterations is a power of two, else 0 */
     uint32_t inside, smooth;
     double prim[3], sec[3]; /* stored r, g, b fields as f64 */
+    uint32_t filter;        /* smooth colouring: try the f32 bracket first (see colour_outside_filtered) */
+    double filt_k;          /* exposure / iterations, any rounding */
+    double filt_d[3];       /* prim[k] * |filt_k| * FR_NU_BRACKET * (1 + 2^-20): the bracket's half-width in byte units */
 };
 
 __device__ __forceinline__ ColourConsts make_colour_consts(const fr_kparams &p) {
@@ -56,7 +59,10 @@ __device__ __forceinline__ ColourConsts make_colour_consts(const fr_kparams &p) 
     for (int k = 0; k < 3; k++) {
         c.prim[k] = p.prim_f[k];
         c.sec[k] = p.sec_f[k];
+        c.filt_d[k] = p.filt_d[k];
     }
+    c.filter = p.colour_filter;
+    c.filt_k = p.filt_k;
     return c;
 }
 
@@ -84,6 +90,44 @@ __device__ __forceinline__ void colour_outside_flat(const ColourConsts &c, uint3
     colour_multiply(c.prim, q * c.exposure, out); /* :228-229 */
 }
 
+/* Smooth colouring without the two f64 software log2s, when that is provably the same bytes.
+ *
+ * The reference computes (calc/src/lib.rs:222-229)
+ *     nu   = log2(log2(sqrt(dist)) / 2)                  [= log2(log2(dist) / 4) over the reals]
+ *     byte = (col * ((iters + 1 - nu) / iterations * exposure)) as u8
+ * and every step after nu is monotone in nu (IEEE add, mul and div by a positive constant are monotone,
+ * so is the truncating cast).  So if nu is known to lie in [a - E, a + E] and the value col * (...) taken
+ * at a, widened by what E and the roundings can move it, stays strictly inside one integer cell, the byte
+ * is decided without knowing nu any better.
+ *
+ * a comes from the hardware's f32 log2 (v_log_f32, twice: 2 + 2 VALU slots instead of ~110 f64
+ * instructions).  Error budget on a, for 2 <= dist <= 2^120 (L = log2(dist) in [1, 120]):
+ *     dist -> f32                 relative 2^-24, i.e. 8.6e-8 absolute on L
+ *     v_log_f32                   <= 1 ulp of L (2^-23 relative)            [measured: fr_debug_math(4)]
+ *     second v_log_f32            relative error of L times 1/ln 2, + 1 ulp of |nu| < 8 (4.8e-7)
+ *     the f64 path's own nu       differs from the real nu by < 1e-14
+ * total < 1e-6; the bracket used is FR_NU_BRACKET = 2^-18 = 3.8e-6 (fr_kernels.h; applied by the host in filt_d).  test_gpu_parity.py scans EVERY f32 in
+ * [2, 2^120] on the device and asserts the composite error of a stays under 1.5e-6.
+ * Pixels outside that range of dist, and pixels whose widened value touches a cell boundary (about one in
+ * 10^5), take the exact path.  Same bytes either way; fr_set_colour_filter(0) forces the exact path. */
+__device__ __forceinline__ bool colour_outside_filtered(const ColourConsts &c, double dist, uint32_t iters_u, uint8_t out[3]) {
+    const bool in_range = dist >= 2.0 && dist <= 0x1p120;
+    const float l1 = __builtin_amdgcn_logf((float)dist);
+    const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
+    const double it2 = ((double)iters_u + 1.0) - (double)nu32; /* iters + 1 is exact */
+    const double m = it2 * c.filt_k;
+    bool same = in_range;
+    const int ch[3] = {0, 2, 1}; /* color_multiply's RGB::new(r, b, g) swap, as in colour_multiply() */
+    for (int k = 0; k < 3; k++) {
+        const double v = c.prim[ch[k]] * m;
+        const double w = __builtin_fma(__builtin_fabs(v), 0x1p-46, c.filt_d[ch[k]]);
+        const uint32_t lo = sat_u8_dev(v - w), hi = sat_u8_dev(v + w);
+        same = same && lo == hi;
+        out[k] = (uint8_t)lo;
+    }
+    return same;
+}
+
 /* `palette` (LDS) is non-NULL only when smooth == false: "LDS-staged palette lookup". */
 __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, uint32_t iters_u,
                                           const double *lds_tab, const uint32_t *palette, uint8_t out[3]) {
@@ -94,12 +138,17 @@ __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, ui
             out[1] = (uint8_t)(v >> 8);
             out[2] = (uint8_t)(v >> 16);
         } else if (c.smooth) {
-            double iters = (double)iters_u;
-            double log_zn = fr_log2_tab(__builtin_sqrt(dist), lds_tab) * 0.5; /* :222, x/2.0 == x*0.5 */
-            double nu = fr_log2_tab(log_zn, lds_tab);                         /* :223 */
-            iters += 1.0 - nu;                                                /* :225 */
-            double q = (c.inv_iterations != 0.0) ? iters * c.inv_iterations : iters / c.iterations_f64;
-            colour_multiply(c.prim, q * c.exposure, out); /* :228-229 */
+            bool exact = true;
+            if (c.filter) exact = !colour_outside_filtered(c, dist, iters_u, out);
+            /* the exact path is ~4x the filter: taken by the whole wave only when one of its lanes needs it */
+            if (__ballot(exact) != 0ull && exact) {
+                double iters = (double)iters_u;
+                double log_zn = fr_log2_tab(__builtin_sqrt(dist), lds_tab) * 0.5; /* :222, x/2.0 == x*0.5 */
+                double nu = fr_log2_tab(log_zn, lds_tab);                         /* :223 */
+                iters += 1.0 - nu;                                                /* :225 */
+                double q = (c.inv_iterations != 0.0) ? iters * c.inv_iterations : iters / c.iterations_f64;
+                colour_multiply(c.prim, q * c.exposure, out); /* :228-229 */
+            }
         } else {
             colour_outside_flat(c, iters_u, out);
         }
@@ -996,6 +1045,260 @@ hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipS
     return launch_refill_form<T, kStripTiles, 0, false>(p, mode, out, grid, stream);
 }
 
+/* ---- work-queue kernel ----------------------------------------------------------------------------
+ *
+ * For views whose orbits are mostly short with a heavy tail (Julia sets: C4's mean is 44 iterations at a
+ * cap of 4096), the strip kernel idles two thirds of its lanes and the patch-refill kernel above still
+ * pays (a) a tail of idle lanes at the end of every 896-pixel patch, (b) a full f64 colour pass — under a
+ * partial EXEC mask — after every episode, and (c) ~60 instructions of bookkeeping per episode.
+ * Here:
+ *   - waves are PERSISTENT and draw 64 x 16-pixel patches from a device-wide atomic counter: a lane's
+ *     pixel outlives its patch, so the only tail is the one at the very end of the image;
+ *   - a finished lane pushes (re, im, escape index, output position) onto a per-wave LDS stack and takes
+ *     the next pixel; the colour map + store runs only when 64 results are waiting — always a FULL wave;
+ *   - a patch's column / row coordinates (calc/src/lib.rs:181-197: 2 IEEE divisions per column and per
+ *     row, not per pixel) are staged in LDS when the patch is opened, so handing a lane its next pixel is
+ *     two LDS reads and two multiplies;
+ *   - the per-lane iteration cap is enforced with one compare per episode; the episode length comes from a
+ *     wave-uniform upper bound of the lanes' counts that is re-derived (a wave reduction) only when it
+ *     reaches the cap.
+ * The scaled loops need every lane of the wave admissible (see "orbit loop, scaled form"); a patch that
+ * is not (it contains the im == 0 row or the re == 0 column) is opened only after the wave has drained,
+ * and runs the unscaled loop.  Results are independent of the schedule: a pixel's orbit never depends on
+ * its lane, its wave or the order of patches. */
+constexpr uint32_t kQPatchW = 64, kQPatchH = 16, kQPatchPx = kQPatchW * kQPatchH;
+constexpr uint32_t kQStack = 128;
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+template <typename T, int M>
+__global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, const fr_kout out, uint32_t npatch_x,
+                                                          uint32_t npatches) {
+    __shared__ T s_x[kQPatchW], s_y[kQPatchH];
+    __shared__ uint32_t s_orow[kQPatchH];
+    __shared__ T q_re[kQStack], q_im[kQStack];
+    __shared__ uint32_t q_it[kQStack], q_px[kQStack], q_py[kQStack];
+    extern __shared__ uint32_t s_dyn_palette[]; /* smooth == false: the palette, staged once */
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *s_pal = nullptr;
+    if (p.palette != nullptr) {
+        for (uint32_t k = lane; k < p.palette_entries; k += 64) s_dyn_palette[k] = p.palette[k];
+        s_pal = s_dyn_palette;
+        __syncthreads();
+    }
+    const double *tab = &g_log2_tab[0][0]; /* the exact colour path is rare here: the table stays in L2 */
+    const ColourConsts cc = make_colour_consts(p);
+    const bool julia = p.algo == 2;
+    const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
+    const T skip_t = (T)p.skip_t;
+    const uint32_t cap = p.iterations;
+    const double width = (double)p.width, height = (double)p.height;
+    const T jre = (T)p.julia_re, jim = (T)p.julia_im;
+
+    /* per-lane orbit state: unscaled (re, im, re^2, im^2, c) or scaled (2re, 2im, X^2, Y^2, 2c) */
+    T a0 = 0, a1 = 0, a2 = 0, a3 = 0, c0 = 0, c1 = 0;
+    uint32_t done = 0, px = 0, py = 0;
+    bool busy = false;
+    /* wave-uniform state */
+    bool scaled = M != 0;      /* loop form of the lanes now running */
+    bool have_patch = false;   /* s_x / s_y hold a patch with unstarted pixels */
+    bool exhausted = false;    /* the counter ran past the last patch */
+    bool held = false;         /* a fetched patch waits for the wave to drain (its loop form differs) */
+    bool held_scaled = false;
+    uint32_t held_id = 0;
+    uint32_t next = 0, vw = 0, vh = 0, pcol0 = 0;
+    uint32_t qcount = 0, upper = 0;
+    T hold_x = 0, hold_y = 0; /* coordinates of the held / just fetched patch: column `lane`, row `lane` */
+    uint32_t hold_orow = 0;
+
+    while (true) {
+        /* ---- hand unstarted pixels to the free lanes, opening patches as needed */
+        unsigned long long busy_mask = __ballot(busy);
+        while (busy_mask != ~0ull) {
+            if (!have_patch) {
+                if (!held) {
+                    if (exhausted) break;
+                    uint32_t id = 0;
+                    if (lane == 0) id = atomicAdd(p.work_counter, 1u);
+                    id = __builtin_amdgcn_readfirstlane(id);
+                    if (id >= npatches) {
+                        exhausted = true;
+                        break;
+                    }
+                    /* the patch's coordinate map (calc/src/lib.rs:182-197), one column and one row per lane */
+                    const uint32_t pyi = id / npatch_x, pxi = id - pyi * npatch_x;
+                    const uint32_t col = pxi * kQPatchW + lane, rr = pyi * kQPatchH + lane;
+                    const uint32_t x = p.x_first + col * p.x_stride;
+                    const uint32_t y = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
+                    const double cx = coord_to_space((double)x, height, (width / height) / 2.0, p.pos_re, p.scale_re);
+                    const double cy = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
+                    hold_x = (T)cx;
+                    hold_y = (T)cy;
+                    hold_orow = p.out_in_place ? y : rr;
+                    held_id = id;
+                    held_scaled = false;
+                    if constexpr (M != 0)
+                        held_scaled = coords_admissible<T>(p, cx, col < p.ncols) &&
+                                      coords_admissible<T>(p, cy, lane < kQPatchH && rr < p.nrows);
+                    held = true;
+                }
+                if (held_scaled != scaled && busy_mask != 0ull) break; /* drain first: one loop form per wave */
+                scaled = held_scaled;
+                const uint32_t pyi = held_id / npatch_x, pxi = held_id - pyi * npatch_x;
+                pcol0 = pxi * kQPatchW;
+                const uint32_t prow0 = pyi * kQPatchH;
+                vw = p.ncols - pcol0 < kQPatchW ? p.ncols - pcol0 : kQPatchW;
+                vh = p.nrows - prow0 < kQPatchH ? p.nrows - prow0 : kQPatchH;
+                __syncthreads(); /* earlier reads of s_x / s_y are done */
+                s_x[lane] = hold_x;
+                if (lane < kQPatchH) {
+                    s_y[lane] = hold_y;
+                    s_orow[lane] = hold_orow;
+                }
+                __syncthreads();
+                held = false;
+                have_patch = true;
+                next = 0;
+            }
+            const unsigned long long free_mask = ~busy_mask;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
+            const uint32_t pix = next + rank;
+            const uint32_t col = pix & (kQPatchW - 1), row = pix >> 6;
+            if (!busy && pix < kQPatchPx && col < vw && row < vh) {
+                const T sx = s_x[col], sy = s_y[row];
+                const T cre = julia ? jre : sx, cim = julia ? jim : sy; /* calc/src/lib.rs:209-210 */
+                if (scaled) {
+                    a0 = sx + sx, a1 = sy + sy, a2 = a0 * a0, a3 = a1 * a1, c0 = cre + cre, c1 = cim + cim;
+                } else {
+                    a0 = sx, a1 = sy, a2 = sx * sx, a3 = sy * sy, c0 = cre, c1 = cim;
+                }
+                px = pcol0 + col;
+                py = s_orow[row];
+                done = 0;
+                busy = true;
+            }
+            next += (uint32_t)__builtin_popcountll(free_mask);
+            if (next >= kQPatchPx || (next >> 6) >= vh) have_patch = false;
+            busy_mask = __ballot(busy);
+        }
+        if (busy_mask == 0ull) {
+            if (exhausted && !held) break;
+            continue; /* drained: the held patch can be opened now */
+        }
+
+        /* ---- one episode */
+        if (upper >= cap) upper = wave_max_u32(busy ? done : 0u); /* every busy lane has done < cap */
+        const uint32_t n = cap - upper;
+        const uint32_t nbusy = (uint32_t)__builtin_popcountll(busy_mask);
+        EpisodeCtl ctl{0u, 0u};
+        if (!(exhausted && !have_patch && !held) && !held) {
+            /* more pixels are waiting: stop once `want` lanes have finished (and minrun iterations were done) */
+            ctl = EpisodeCtl{nbusy > p.queue_want ? nbusy - p.queue_want : 0u, p.queue_minrun};
+        }
+        uint32_t it = 0, completed = 0;
+        if (busy) {
+            if constexpr (M != 0) {
+                if (scaled)
+                    it = orbit_scaled_run<T, M, false>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed);
+                else
+                    it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
+            } else {
+                it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
+            }
+        }
+        /* wave-uniform, but assigned under `if (busy)`: take it from a lane that ran the episode */
+        completed = __builtin_amdgcn_readlane(completed, (int)__builtin_ctzll(busy_mask));
+        upper += completed;
+
+        /* ---- retire: finished lanes push their result and become free */
+        bool fin = false;
+        uint32_t iters = 0;
+        if (busy) {
+            const bool escaped = it < completed;
+            iters = escaped ? done + it : cap;
+            done += completed;
+            fin = escaped || done >= cap;
+        }
+        const unsigned long long fin_mask = __ballot(fin);
+        if (fin_mask != 0ull) {
+            if (fin) {
+                const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(fin_mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)fin_mask, 0u));
+                q_re[slot] = scaled ? a0 * (T)0.5 : a0; /* exact */
+                q_im[slot] = scaled ? a1 * (T)0.5 : a1;
+                q_it[slot] = iters;
+                q_px[slot] = px;
+                q_py[slot] = py;
+                busy = false;
+            }
+            qcount += (uint32_t)__builtin_popcountll(fin_mask);
+            if (qcount >= 64u) {
+                /* colour map + store of 64 waiting results: a full wave */
+                __syncthreads();
+                const uint32_t e = qcount - 64u + lane;
+                const double zre = (double)q_re[e], zim = (double)q_im[e];
+                uint8_t rgb[3];
+                colour_of(cc, zre * zre + zim * zim, q_it[e], tab, s_pal, rgb); /* pos.squared_distance(), :214 */
+                store_pixel(p, out.rgb, q_py[e], q_px[e], rgb);
+                qcount -= 64u;
+                __syncthreads();
+            }
+        }
+    }
+    /* ---- the last, partial batch */
+    __syncthreads();
+    if (lane < qcount) {
+        const double zre = (double)q_re[lane], zim = (double)q_im[lane];
+        uint8_t rgb[3];
+        colour_of(cc, zre * zre + zim * zim, q_it[lane], tab, s_pal, rgb);
+        store_pixel(p, out.rgb, q_py[lane], q_px[lane], rgb);
+    }
+}
+
+template <typename T, int M>
+hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
+    const uint64_t npx = ((uint64_t)p.ncols + kQPatchW - 1) / kQPatchW;
+    const uint64_t npy = ((uint64_t)p.nrows + kQPatchH - 1) / kQPatchH;
+    if (npx * npy == 0) return hipSuccess;
+    if (npx * npy > 0xFFFFFF00ull) return hipErrorInvalidConfiguration;
+    const size_t dyn = p.palette ? sizeof(uint32_t) * p.palette_entries : 0;
+    /* persistent grid: as many one-wave workgroups as the device holds at once (asking for a few more
+     * than that is harmless: a late workgroup finds the counter exhausted and leaves) */
+    static thread_local int cached_device = -1, cached_cus = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != cached_device) {
+        if ((e = hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        cached_device = dev;
+    }
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, escape_queue_kernel<T, M>, 64, dyn);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 32) per_cu = 32;
+    uint64_t grid = (uint64_t)per_cu * (uint64_t)cached_cus;
+    if (grid > npx * npy) grid = npx * npy;
+    hipLaunchKernelGGL((escape_queue_kernel<T, M>), dim3((uint32_t)grid), dim3(64), dyn, stream, p, out, (uint32_t)npx,
+                       (uint32_t)(npx * npy));
+    return hipGetLastError();
+}
+
+/* RGB output only; needs p.work_counter (zeroed on the launch stream by the caller) */
+template <typename T>
+hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
+    if (p.loop_mode == 4) return launch_queue_form<T, 4>(p, out, stream);
+    if (p.loop_mode == 2) return launch_queue_form<T, 2>(p, out, stream);
+    return launch_queue_form<T, 0>(p, out, stream);
+}
+
 template <typename T, int kStripTiles>
 hipError_t launch_strips(const fr_kparams &p, int mode, const fr_kout &out, hipStream_t stream) {
     if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
@@ -1069,6 +1372,10 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
+            if (p.algo == 2 && mode == FR_OUT_RGB && p.work_counter && !p.cycle_shortcut) {
+                name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x16-px patches");
+                return launch_queue<T>(p, out, stream);
+            }
             if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) {
                 name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
                 return launch_refill<T, 7>(p, mode, out, stream);
@@ -1090,7 +1397,12 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
     case 8:
         name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
-    case 10: /* TODO queue kernel */
+    case 10: /* the work-queue kernel (RGB output of an escape-time algorithm; otherwise as 9) */
+        if ((p.algo == 0 || p.algo == 2) && mode == FR_OUT_RGB && p.work_counter && !p.cycle_shortcut) {
+            name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x16-px patches");
+            return launch_queue<T>(p, out, stream);
+        }
+        [[fallthrough]];
     case 9: /* refilling strips; only the escape-time algorithms have orbits to refill */
         if (p.algo != 0 && p.algo != 2) {
             name = FR_KNAME("escape_strip_kernel", "7 tiles");
@@ -1180,7 +1492,41 @@ __global__ __launch_bounds__(256) void math_probe_kernel(int which, const double
     out[k] = y;
 }
 
+/* Test hook: the colour filter's bracket centre against the f64 path's nu, for EVERY f32 with bit pattern in
+ * [lo, hi] (as the (float)dist of colour_outside_filtered): out[0] = the largest |nu32 - nu| seen. */
+__global__ __launch_bounds__(256) void nu_scan_kernel(uint32_t lo, uint32_t hi, unsigned long long *worst_bits) {
+    __shared__ double s_tab[FR_LOG2_N * 3];
+    const double *gt = &g_log2_tab[0][0];
+    for (uint32_t k = threadIdx.x; k < FR_LOG2_N * 3; k += 256) s_tab[k] = gt[k];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    double worst = 0.0;
+    for (uint64_t b = (uint64_t)lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; b <= hi; b += stride) {
+        const float d = __builtin_bit_cast(float, (uint32_t)b);
+        const float nu32 = __builtin_amdgcn_logf(__builtin_amdgcn_logf(d) * 0.25f);
+        const double nu = fr_log2_tab(fr_log2_tab(__builtin_sqrt((double)d), s_tab) * 0.5, s_tab);
+        const double err = __builtin_fabs((double)nu32 - nu);
+        worst = err > worst || err != err ? err : worst;
+    }
+    atomicMax(worst_bits, (unsigned long long)fr_bits_of(worst)); /* non-negative doubles order like their bits */
+}
+
 } /* namespace */
+
+bool fr_wants_work_queue(const fr_kparams &p, int tile) {
+    if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
+    if (tile == 10) return true;
+    if (tile != 0 || p.algo != 2) return false;
+    return (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8) >= 262144;
+}
+
+hipError_t fr_launch_nu_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nu_scan_kernel, dim3(256 * 16), dim3(256), 0, stream, lo_bits, hi_bits,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
 
 hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const fr_kout &out, int tile,
                             hipStream_t stream, const char **kernel_name) {

@@ -20,6 +20,7 @@
  */
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -215,6 +216,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     Ctx &ctx = w.ctx;
     const uint32_t r = (uint32_t)w.index, n = j.n;
     const size_t row_bytes = (size_t)3 * j.cfg->width;
+    const size_t need_total = row_bytes * (size_t)j.cfg->height;
     HIP_TRY(hipSetDevice(ctx.hip_device));
     const bool in_place = j.sink != Sink::Host && r == 0; /* the root renders straight into the image */
     const uint64_t my_rows = fr_block_cyclic_rows(j.cfg->height, j.block_rows, r, n);
@@ -324,7 +326,16 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
                     deferred.emplace_back(dst_off, off);
                     deferred_len.push_back(bytes);
                 } else {
-                    HIP_TRY(hipMemcpyAsync(j.dst + dst_off, scratch + off, bytes, hipMemcpyDeviceToHost, ctx.copy_stream));
+                    /* one DMA must not span two pins: split the block where the pinner's chunks end */
+                    size_t done_b = 0;
+                    while (done_b < bytes) {
+                        size_t ca = 0, cb = 0; /* the chunk [ca, cb) that holds byte dst_off + done_b */
+                        while ((cb = ChunkPinner::chunk_end(j.dst, need_total, ca)) <= dst_off + done_b) ca = cb;
+                        const size_t part = std::min(bytes - done_b, cb - (dst_off + done_b));
+                        HIP_TRY(hipMemcpyAsync(j.dst + dst_off + done_b, scratch + off + done_b, part, hipMemcpyDeviceToHost,
+                                               ctx.copy_stream));
+                        done_b += part;
+                    }
                 }
             }
             off += bytes;

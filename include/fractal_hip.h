@@ -322,7 +322,8 @@ int fr_set_loop_mode(int mode);
 
 /* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
  * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n], 3: the `as u8` cast —
- * so tests can compare the device's roundings with the host's. */
+ * so tests can compare the device's roundings with the host's; which = 4: the colour filter's
+ * bracket centre against the f64 nu over EVERY f32 bit pattern in [in[0], in[1]], out[0] = worst error. */
 int fr_debug_math(int which, const double *in, double *out, size_t n);
 
 #ifdef __cplusplus

@@ -1,0 +1,326 @@
+"""Round-2 kernel work, through the C ABI on the GPU box, against the oracle:
+  * contraction-sensitive known-answer tests (tests/exact_model.py) on every orbit-loop form,
+  * the colour filter (f32 bracket of nu + exact fallback): its bracket scanned over EVERY f32, and byte
+    identity with the always-exact path,
+  * the work-queue kernel (persistent waves, LDS result stack): byte identity with the oracle on ragged,
+    tiny, in-place / block-cyclic, palette, RGBA and mode-switching cases, and at BASELINE C4's full size,
+  * the scaled loop's admissibility boundaries (limit 2^400, |c| at 2^-300 / 2^400; f32 2^+-30).
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import exact_model as M
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fr():
+    import torch  # noqa: F401  (first: see INTEGRATION.md §4)
+
+    import fractal_renderer_amd
+
+    assert fractal_renderer_amd.device_count() > 0, "no HIP device: the GPU tests need a real MI355X"
+    fractal_renderer_amd.init(0)
+    return fractal_renderer_amd
+
+
+@pytest.fixture(scope="module")
+def lib(fr):
+    from fractal_renderer_amd import _native
+
+    return _native.load()
+
+
+def to_fr(fr, ocfg):
+    return fr.Config.from_buffer_copy(bytes(ocfg))
+
+
+def f32_bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+# ---- contraction-sensitive KATs on the device -----------------------------------------------------
+
+
+def one_pixel_config(re, im, iterations, limit):
+    """A 1x1 image whose only pixel is EXACTLY (re, im): coordinate = (0/1 - 0.5)/1 + pos with
+    pos = v + 0.5, both steps exact for the KAT inputs (find_contraction_kats.py picked them so)."""
+    return O.cli_config(1, 1, iterations=iterations, limit=limit, pos=(re + 0.5, im + 0.5), scale=(1.0, 1.0))
+
+
+@pytest.mark.parametrize("fmt,kats", [("f64", M.CONTRACTION_KATS_F64), ("f32", M.CONTRACTION_KATS_F32)])
+def test_contraction_sensitive_kats_on_every_loop_form(fr, lib, fmt, kats):
+    """fl(fl(re*re) - fl(im*im)) etc. exactly as the reference rounds them (calc/src/lib.rs:88-89, 95,
+    103-104): expected values from exact rational arithmetic, on the unscaled loop, both scaled loops
+    (whose single fma is exact by construction) and the batch entry point."""
+    from fractal_renderer_amd import _native
+
+    prec = fr.Precision.F32 if fmt == "f32" else fr.Precision.F64
+    for n, re, im, limit in kats:
+        want = M.recursive(n, (re, im), (re, im), limit, fmt)
+        pos, it = fr.recursive_batch(n, [(re, im)], [(re, im)], limit, prec)
+        assert (pos[0, 0], pos[0, 1], int(it[0])) == (want[0][0], want[0][1], want[1]), ("batch", n, re, im)
+        ocfg = one_pixel_config(re, im, n, limit)
+        assert O.lib().fro_xy_to_imaginary(C.byref(ocfg), 0, 0).re == re
+        assert O.lib().fro_xy_to_imaginary(C.byref(ocfg), 0, 0).im == im
+        cfg = to_fr(fr, ocfg)
+        for mode in (0, 2, 4):
+            for tile in (0, 9, 10, 808):
+                try:
+                    _native.check(lib.fr_set_loop_mode(mode))
+                    _native.check(lib.fr_set_tile(tile))
+                    z, iters = fr.escape_rows(cfg, 0, 1, prec)
+                finally:
+                    lib.fr_set_loop_mode(-1)
+                    lib.fr_set_tile(0)
+                assert (z[0, 0, 0], z[0, 0, 1], int(iters[0, 0])) == (want[0][0], want[0][1], want[1]), (mode, tile, n, re, im)
+
+
+# ---- the colour filter ---------------------------------------------------------------------------
+
+
+def test_colour_filter_bracket_holds_for_every_f32(fr, lib):
+    """The filter brackets nu = log2(log2(sqrt(dist))/2) by its f32 estimate +- 2^-18.  Scan EVERY f32
+    value of (float)dist in [2, 2^120] on the device: the estimate is within 1.5e-6 of the f64 path's nu
+    (which leaves > 2x margin for the f64->f32 conversion of dist, 1.3e-7, and everything else)."""
+    from fractal_renderer_amd import _native
+
+    x = np.array([float(f32_bits(2.0)), float(f32_bits(2.0 ** 120))])
+    y = np.zeros(2)
+    _native.check(lib.fr_debug_math(4, x.ctypes.data, y.ctypes.data, 2))
+    assert 0.0 < y[0] < 1.5e-6, y[0]
+    assert y[0] + 1.3e-7 + 1e-12 < 2.0 ** -18
+
+
+FILTER_CASES = [
+    dict(width=640, height=480, iterations=200),
+    dict(width=333, height=257, iterations=3, exposure=50.0),
+    dict(width=333, height=257, iterations=1),
+    dict(width=400, height=300, iterations=1024, exposure=255.0, primary_color=(255, 255, 255)),
+    dict(width=400, height=300, iterations=50, exposure=-1.0),
+    dict(width=400, height=300, iterations=50, exposure=1e-3),
+    dict(width=400, height=300, iterations=77, stable_limit=0.5),   # dist in (0.5, 2): outside the filter's range
+    dict(width=400, height=300, iterations=77, stable_limit=0.0, limit=2.0),
+    dict(width=400, height=300, iterations=60, limit=1.5, stable_limit=30.0),
+    dict(width=400, height=300, iterations=90, limit=1e30),          # dist up to 1e60+: beyond 2^120 -> exact path
+    dict(width=512, height=512, iterations=300, scale=(1e6, 1e6), pos=(-0.7436447860, 0.1318252536)),
+    dict(width=400, height=300, iterations=120, algo=O.JULIA, julia_set=(-0.8, 0.156)),
+    dict(width=400, height=300, iterations=40, exposure=float("inf")),   # filter must switch itself off
+    dict(width=400, height=300, iterations=40, exposure=float("nan")),
+    dict(width=200, height=100, iterations=0),
+]
+
+
+@pytest.mark.parametrize("case", FILTER_CASES)
+def test_colour_filter_gives_the_exact_paths_bytes(fr, case):
+    kw = dict(case)
+    w, h, algo = kw.pop("width"), kw.pop("height"), kw.pop("algo", O.MANDELBROT)
+    ocfg = O.cli_config(w, h, algo, **kw)
+    cfg = to_fr(fr, ocfg)
+    want = O.get_image(ocfg)  # libm log2: what the reference calls
+    for prec in (fr.Precision.F64, fr.Precision.F32):
+        w32 = want if prec == fr.Precision.F64 else O.get_image(ocfg, O.F32)
+        on = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=1))
+        off = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=0))
+        assert np.array_equal(on, off), (case, prec)
+        assert np.array_equal(on, w32), (case, prec)
+
+
+def test_colour_filter_full_size_c2_identical(fr, lib):
+    """BASELINE C2 (16384^2): filter on and off give the same 805 306 368 bytes."""
+    import torch
+    from fractal_renderer_amd import _native
+
+    cfg = to_fr(fr, O.cli_config(16384, 16384, iterations=1024))
+    need = 3 * 16384 * 16384
+    s = torch.cuda.current_stream()
+    imgs = []
+    for flt in (1, 0):
+        d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        o = fr.RenderOpts(colour_filter=flt)
+        _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), 0, 0, 16384, d.data_ptr(), need, s.cuda_stream,
+                                                          C.byref(o)))
+        imgs.append(d)
+    torch.cuda.synchronize()
+    assert torch.equal(imgs[0], imgs[1])
+
+
+# ---- the work-queue kernel (tile = 10) --------------------------------------------------------------
+
+QUEUE_CASES = [
+    dict(width=1237, height=1001, iterations=300, algo=O.JULIA, julia_set=(-0.8, 0.156)),       # ragged both ways
+    dict(width=64, height=16, iterations=100, algo=O.JULIA, julia_set=(-0.8, 0.156)),           # exactly one patch
+    dict(width=65, height=17, iterations=100, algo=O.JULIA, julia_set=(0.285, 0.01)),           # one px over in both
+    dict(width=3, height=2, iterations=50),                                                     # smaller than a patch row
+    dict(width=700, height=520, iterations=400),                                                # Mandelbrot: lanes hit the cap
+    dict(width=700, height=520, iterations=400, smooth=0),                                      # palette in dynamic LDS
+    dict(width=700, height=520, iterations=2000, smooth=0, inside=0),                           # palette too large: per pixel
+    dict(width=512, height=512, iterations=1, algo=O.JULIA, julia_set=(-0.8, 0.156)),
+    dict(width=512, height=512, iterations=0),
+    dict(width=800, height=600, iterations=250, algo=O.JULIA, julia_set=(0.0, 0.0)),            # c = 0: never admissible
+    dict(width=800, height=600, iterations=250, algo=O.JULIA, julia_set=(-0.8, 0.156), pos=(0.3, -0.2), scale=(3.0, 0.7)),
+    dict(width=1024, height=512, iterations=5000, algo=O.JULIA, julia_set=(-0.4, 0.6)),         # connected set: long orbits
+    dict(width=900, height=700, iterations=300, limit=2.0),                                     # loop plan falls back
+    dict(width=640, height=480, iterations=120, algo=O.BARNSLEY_FERN),                          # BLACK (calc/src/lib.rs:211)
+]
+
+
+@pytest.mark.parametrize("case", QUEUE_CASES)
+def test_work_queue_kernel_matches_the_oracle(fr, case):
+    kw = dict(case)
+    w, h, algo = kw.pop("width"), kw.pop("height"), kw.pop("algo", O.MANDELBROT)
+    ocfg = O.cli_config(w, h, algo, **kw)
+    cfg = to_fr(fr, ocfg)
+    for prec, oprec in ((fr.Precision.F64, O.F64), (fr.Precision.F32, O.F32)):
+        want = O.get_image(ocfg, oprec)
+        for loop_mode in (-1, 0, 2):
+            got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=10, loop_mode=loop_mode))
+            assert np.array_equal(got, want), (case, prec, loop_mode)
+        for minrun, quit16 in ((0, 1), (3, 16), (64, 4)):
+            got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=10, refill_minrun=minrun, refill_quit16=quit16))
+            assert np.array_equal(got, want), (case, prec, minrun, quit16)
+
+
+def test_work_queue_kernel_row_bands_rgba_and_in_place_blocks(fr, lib):
+    import torch
+    from fractal_renderer_amd import _native
+
+    ocfg = O.cli_config(777, 613, O.JULIA, julia_set=(-0.8, 0.156), iterations=350)
+    cfg = to_fr(fr, ocfg)
+    want = O.get_image(ocfg)
+    o = fr.RenderOpts(tile=10)
+    # row bands rendered on their own
+    for y0, y1 in ((0, 613), (100, 117), (600, 613), (5, 6)):
+        assert np.array_equal(fr.get_image_rows(cfg, y0, y1, 0, opts=o), want[y0:y1])
+    s = torch.cuda.current_stream()
+    # RGBA8
+    d = torch.zeros(613 * 777 * 4, dtype=torch.uint8, device="cuda:0")
+    _native.check(lib.fr_render_rows_rgba8_device_opts(C.byref(cfg), 0, 0, 613, d.data_ptr(), d.numel(), s.cuda_stream,
+                                                       C.byref(o)))
+    rgba = d.cpu().numpy().reshape(613, 777, 4)
+    assert np.array_equal(rgba[..., :3], want) and (rgba[..., 3] == 255).all()
+    # block-cyclic shares rendered IN PLACE into one image (what a multi-GPU root does), 3 shares
+    img = torch.zeros(613 * 777 * 3, dtype=torch.uint8, device="cuda:0")
+    for r in range(3):
+        rows = C.c_uint64(0)
+        _native.check(lib.fr_render_block_cyclic_range_rgb8_device_opts(
+            C.byref(cfg), 0, 16, r, 3, 0, 1, img.data_ptr(), img.numel(), s.cuda_stream, C.byref(rows), C.byref(o)))
+    assert np.array_equal(img.cpu().numpy().reshape(613, 777, 3), want)
+    # and packed
+    for r in range(3):
+        rows = C.c_uint64(0)
+        nrows = lib.fr_block_cyclic_rows(613, 16, r, 3)
+        part = torch.zeros(nrows * 777 * 3, dtype=torch.uint8, device="cuda:0")
+        _native.check(lib.fr_render_block_cyclic_range_rgb8_device_opts(
+            C.byref(cfg), 0, 16, r, 3, 0, 0, part.data_ptr(), part.numel(), s.cuda_stream, C.byref(rows), C.byref(o)))
+        got = part.cpu().numpy().reshape(nrows, 777, 3)
+        idx = [y for b in range(r, (613 + 15) // 16, 3) for y in range(b * 16, min(613, b * 16 + 16))]
+        assert rows.value == nrows and np.array_equal(got, want[idx])
+
+
+@pytest.mark.parametrize("prec_name", ["f32", "f64"])
+def test_full_size_c4_work_queue_kernel(fr, lib, prec_name):
+    """BASELINE C4 (Julia, 16384^2, 4096 iterations) through the default dispatch = the work-queue kernel:
+    every 16th pixel against the oracle (libm log2), the 180-degree symmetry of the Julia image, and byte
+    identity with the patch-refill kernel (tile 9) and with the colour filter off."""
+    import torch
+    from fractal_renderer_amd import _native
+
+    ocfg = O.cli_config(16384, 16384, O.JULIA, julia_set=(-0.8, 0.156), iterations=4096)
+    cfg = to_fr(fr, ocfg)
+    prec = 1 if prec_name == "f32" else 0
+    need = 3 * 16384 * 16384
+    s = torch.cuda.current_stream()
+
+    def render(**kw):
+        d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        o = fr.RenderOpts(**kw)
+        _native.check(lib.fr_set_profiling(1))
+        _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), prec, 0, 16384, d.data_ptr(), need, s.cuda_stream,
+                                                          C.byref(o)))
+        name = C.create_string_buffer(160)
+        _native.check(lib.fr_last_kernel_name(name, len(name)))
+        _native.check(lib.fr_set_profiling(0))
+        return d, name.value
+
+    img, name = render()
+    assert name.startswith(b"escape_queue_kernel"), name
+    torch.cuda.synchronize()
+    total, npx, want = O.sample_image(ocfg, 16, 16, O.F32 if prec else O.F64)
+    view = img.view(16384, 16384, 3)
+    assert np.array_equal(view[::16, ::16].cpu().numpy(), want)
+    assert torch.equal(view[1:, 1:], torch.flip(view[1:, 1:], dims=(0, 1)))
+    other, name9 = render(tile=9)
+    assert name9.startswith(b"escape_refill_kernel"), name9
+    assert torch.equal(img, other)
+    del other
+    exact, _ = render(colour_filter=0)
+    assert torch.equal(img, exact)
+
+
+# ---- the scaled loop at the edges of its admissible range ---------------------------------------------
+
+
+def _escape(fr, lib, ocfg, prec, mode):
+    from fractal_renderer_amd import _native
+
+    cfg = to_fr(fr, ocfg)
+    try:
+        _native.check(lib.fr_set_loop_mode(mode))
+        return fr.escape_rows(cfg, 0, cfg.height, prec)
+    finally:
+        lib.fr_set_loop_mode(-1)
+
+
+@pytest.mark.parametrize("limit", [2.0 ** 400, float(np.nextafter(2.0 ** 400, np.inf)), 2.0 ** 399, 2.0 ** 401])
+def test_scaled_loop_limit_boundary_f64(fr, lib, limit):
+    """The host admits the scaled loop only for |limit| <= 2^400 (f64); at the boundary and one ulp past
+    it every loop form still gives the oracle's (z, iters) bit for bit."""
+    ocfg = O.cli_config(96, 64, iterations=40, limit=limit)
+    wz, wit = O.escape_rows(ocfg)
+    for mode in (-1, 0, 2, 4):
+        z, it = _escape(fr, lib, ocfg, fr.Precision.F64, mode)
+        assert np.array_equal(it, wit) and np.array_equal(z.view(np.uint64), wz.view(np.uint64)), (limit, mode)
+
+
+@pytest.mark.parametrize("limit", [2.0 ** 30, float(np.nextafter(np.float32(2.0 ** 30), np.float32(np.inf))), 2.0 ** 31])
+def test_scaled_loop_limit_boundary_f32(fr, lib, limit):
+    ocfg = O.cli_config(96, 64, iterations=40, limit=limit)
+    wz, wit = O.escape_rows(ocfg, O.F32)
+    for mode in (-1, 0, 2, 4):
+        z, it = _escape(fr, lib, ocfg, fr.Precision.F32, mode)
+        assert np.array_equal(it, wit) and np.array_equal(z.view(np.uint64), wz.view(np.uint64)), (limit, mode)
+
+
+@pytest.mark.parametrize("mag", [2.0 ** -300, float(np.nextafter(2.0 ** -300, 0.0)), 2.0 ** -299, 2.0 ** 400,
+                                 float(np.nextafter(2.0 ** 400, np.inf)), 2.0 ** -1000, 5e-324])
+def test_scaled_loop_c_magnitude_boundary_f64(fr, lib, mag):
+    """Lanes are admitted to the scaled loop only if every |c| component lies in [2^-300, 2^400]: Julia
+    constants exactly at, one ulp inside and one ulp outside both ends (and deep in the subnormal
+    range), on the scaled and unscaled forms, against the oracle."""
+    for jset in ((mag, 0.3), (-0.4, mag), (mag, -mag)):
+        ocfg = O.cli_config(80, 48, O.JULIA, julia_set=jset, iterations=30, limit=2.0 ** 390 if mag > 1 else 65536.0)
+        wz, wit = O.escape_rows(ocfg)
+        for mode in (-1, 0, 4):
+            z, it = _escape(fr, lib, ocfg, fr.Precision.F64, mode)
+            nan = np.isnan(wz)
+            assert np.array_equal(it, wit), (mag, jset, mode)
+            assert np.array_equal(nan, np.isnan(z)) and np.array_equal(z.view(np.uint64)[~nan], wz.view(np.uint64)[~nan])
+
+
+@pytest.mark.parametrize("mag", [2.0 ** -30, float(np.nextafter(np.float32(2.0 ** -30), np.float32(0))), 2.0 ** 30,
+                                 float(np.nextafter(np.float32(2.0 ** 30), np.float32(np.inf))), 2.0 ** -140])
+def test_scaled_loop_c_magnitude_boundary_f32(fr, lib, mag):
+    for jset in ((mag, 0.3), (-0.4, mag)):
+        ocfg = O.cli_config(80, 48, O.JULIA, julia_set=jset, iterations=30, limit=2.0 ** 28 if mag > 1 else 65536.0)
+        wz, wit = O.escape_rows(ocfg, O.F32)
+        for mode in (-1, 0, 4):
+            z, it = _escape(fr, lib, ocfg, fr.Precision.F32, mode)
+            nan = np.isnan(wz)
+            assert np.array_equal(it, wit), (mag, jset, mode)
+            assert np.array_equal(nan, np.isnan(z)) and np.array_equal(z.view(np.uint64)[~nan], wz.view(np.uint64)[~nan])

@@ -679,17 +679,27 @@ def test_concurrent_callers(fr):
 # ---- BASELINE.json full sizes: size-independent properties + strided comparison ---------------
 
 
+def oracle_sample_both_modes(ocfg, step, prec=O.F64):
+    """The oracle on every `step`-th pixel in x and y with the platform libm's log2 — what the reference's
+    f64::log2 calls (calc/src/lib.rs:222-223), the mode the device is compared with — after checking that the
+    software log2 the kernels carry gives the very same bytes and iteration sum on that sample."""
+    O.set_log2_mode(O.LOG2_SOFT)
+    try:
+        soft = O.sample_image(ocfg, step, step, prec)
+    finally:
+        O.set_log2_mode(O.LOG2_LIBM)
+    libm = O.sample_image(ocfg, step, step, prec)
+    assert soft[:2] == libm[:2] and np.array_equal(soft[2], libm[2]), "libm and software log2 differ in output bytes"
+    return libm
+
+
 def test_full_size_c2_sampled_against_oracle(fr):
     """C2 (16384^2, 1024 iterations): every 16th pixel in x and y, colours and executed-iteration
     sum, against the oracle; plus row-split invariance of the full image."""
     ocfg = O.cli_config(16384, 16384, iterations=1024)
     cfg = to_fr(fr, ocfg)
     img = fr.get_image(cfg)
-    O.set_log2_mode(O.LOG2_SOFT)
-    try:
-        total, npx, want = O.sample_image(ocfg, 16, 16)
-    finally:
-        O.set_log2_mode(O.LOG2_LIBM)
+    total, npx, want = oracle_sample_both_modes(ocfg, 16)
     assert np.array_equal(img[::16, ::16], want)
     assert fr.count_iterations(cfg, sx=16, sy=16) == (total, npx)
     # vertical symmetry of the default view about row 8192 (im(y) = -im(16384 - y) exactly and the
@@ -706,11 +716,7 @@ def test_full_size_c4_julia_f32_sampled_against_oracle(fr):
     ocfg = O.cli_config(16384, 16384, O.JULIA, julia_set=(-0.8, 0.156), iterations=4096)
     cfg = to_fr(fr, ocfg)
     img = fr.get_image(cfg, fr.Precision.F32)
-    O.set_log2_mode(O.LOG2_SOFT)
-    try:
-        total, npx, want = O.sample_image(ocfg, 16, 16, O.F32)
-    finally:
-        O.set_log2_mode(O.LOG2_LIBM)
+    total, npx, want = oracle_sample_both_modes(ocfg, 16, O.F32)
     assert np.array_equal(img[::16, ::16], want)
     assert fr.count_iterations(cfg, sx=16, sy=16, precision=fr.Precision.F32) == (total, npx)
     # the Julia set of a c is symmetric under z -> -z: the image equals itself rotated by 180 degrees
@@ -726,11 +732,7 @@ def test_full_size_c3_deep_zoom_sampled_and_shortcut(fr):
     ocfg = O.cli_config(16384, 16384, iterations=65536, scale=(1e6, 1e6), pos=(-0.7436447860, 0.1318252536))
     cfg = to_fr(fr, ocfg)
     img = fr.get_image(cfg)
-    O.set_log2_mode(O.LOG2_SOFT)
-    try:
-        total, npx, want = O.sample_image(ocfg, 64, 64)
-    finally:
-        O.set_log2_mode(O.LOG2_LIBM)
+    total, npx, want = oracle_sample_both_modes(ocfg, 64)
     assert np.array_equal(img[::64, ::64], want)
     assert fr.count_iterations(cfg, sx=64, sy=64) == (total, npx)
     lib = _native.load()
@@ -748,11 +750,7 @@ def test_full_size_c5_65536_squared_on_one_device(fr):
     ocfg = O.cli_config(65536, 65536, iterations=1024)
     cfg = to_fr(fr, ocfg)
     img = fr.get_image(cfg)
-    O.set_log2_mode(O.LOG2_SOFT)
-    try:
-        total, npx, want = O.sample_image(ocfg, 64, 64)
-    finally:
-        O.set_log2_mode(O.LOG2_LIBM)
+    total, npx, want = oracle_sample_both_modes(ocfg, 64)
     assert np.array_equal(img[::64, ::64], want)
     assert fr.count_iterations(cfg, sx=64, sy=64) == (total, npx)
     assert np.array_equal(img[1:4096], img[65535:61440:-1])          # top rows mirror the bottom rows
