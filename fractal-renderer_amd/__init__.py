@@ -27,7 +27,7 @@ __all__ = [
     "Algo", "Config", "Imaginary", "RGB", "Precision", "FractalHipError",
     "get_image", "get_image_rows", "get_image_rgba", "get_recursive_pixel", "recursive", "recursive_batch",
     "escape_rows", "colour_image", "count_iterations", "init", "shutdown", "device_count", "device_name",
-    "RenderOpts", "init_devices", "get_image_multi", "multi_stats", "build_id",
+    "RenderOpts", "init_devices", "get_image_multi", "multi_stats", "build_id", "get_image_fern",
 ]
 
 
@@ -154,6 +154,15 @@ def get_image(config, precision=Precision.F64):
         _native.check(_native.load().fr_render_rgb8(C.byref(config), out.ctypes.data, out.nbytes))
         return out
     return get_image_rows(config, 0, config.height, precision, out)
+
+
+def get_image_fern(config, threads=1, seed=0, walkers=0):
+    """get_image's Algo::BarnsleyFern arm (src/lib.rs:271-319, 417-463) on the GPU: uint8 [height, width, 3].
+    threads = the rayon thread count being modelled (the reference returns ONE thread's image of
+    iterations / threads points); seed keys the build's deterministic RNG; walkers = parallel orbits (0 = auto)."""
+    out = np.empty((config.height, config.width, 3), dtype=np.uint8)
+    _native.check(_native.load().fr_render_fern_rgb8(C.byref(config), threads, seed, walkers, out.ctypes.data, out.nbytes))
+    return out
 
 
 def get_image_rgba(config, precision=Precision.F64):

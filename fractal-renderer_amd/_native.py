@@ -127,6 +127,7 @@ PROTOTYPES = {
         [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
          C.c_void_p, C.POINTER(C.c_uint64), _OPTS],
     ),
+    "fr_render_fern_rgb8": (C.c_int, [C.POINTER(fr_config), C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t]),
     "fr_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "fr_multi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "fr_render_rgb8_multi": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]),

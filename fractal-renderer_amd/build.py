@@ -16,7 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libfractal_hip.so")
 ID_PATH = LIB_PATH + ".id"
-SOURCES = ["fr_kernels.hip", "fr_api.hip", "fr_host.hip", "fr_multi.hip"]
+SOURCES = ["fr_kernels.hip", "fr_api.hip", "fr_host.hip", "fr_multi.hip", "fr_fern.hip"]
 DEPS = SOURCES + ["fr_kernels.h", "fr_ctx.h", "fr_math.h", "fr_log2_table.inc",
                   os.path.join("..", "..", "include", "fractal_hip.h")]
 HIPCC_FLAGS = [

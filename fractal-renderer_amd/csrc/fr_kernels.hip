@@ -48,7 +48,8 @@ struct ColourConsts {
     double filt_d[3];       /* prim[k] * |filt_k| * FR_NU_BRACKET * (1 + 2^-20): the bracket's half-width in byte units */
 };
 
-__device__ __forceinline__ ColourConsts make_colour_consts(const fr_kparams &p) {
+template <typename P>
+__device__ __forceinline__ ColourConsts make_colour_consts(const P &p) {
     ColourConsts c;
     c.stable_limit = p.stable_limit;
     c.exposure = p.exposure;
@@ -583,10 +584,10 @@ __device__ __forceinline__ double coord_to_space(double coord, double max, doubl
 }
 
 /* store one finished pixel: packed r,g,b at 3*(row*ncols + col), or one r,g,b,255 dword at 4*(...) */
-__device__ __forceinline__ void store_pixel(const fr_kparams &p, uint8_t *base, uint32_t row, uint32_t col,
+__device__ __forceinline__ void store_pixel(uint32_t ncols, uint32_t out_rgba, uint8_t *base, uint32_t row, uint32_t col,
                                             const uint8_t rgb[3]) {
-    const uint64_t k = (uint64_t)row * p.ncols + col;
-    if (p.out_rgba) {
+    const uint64_t k = (uint64_t)row * ncols + col;
+    if (out_rgba) {
         reinterpret_cast<uint32_t *>(base)[k] =
             (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16) | 0xFF000000u;
     } else {
@@ -595,6 +596,9 @@ __device__ __forceinline__ void store_pixel(const fr_kparams &p, uint8_t *base, 
         o[1] = rgb[1];
         o[2] = rgb[2];
     }
+}
+__device__ __forceinline__ void store_pixel(const fr_kparams &p, uint8_t *base, uint32_t row, uint32_t col, const uint8_t rgb[3]) {
+    store_pixel(p.ncols, p.out_rgba, base, row, col, rgb);
 }
 
 /* One pixel per lane, from its start coordinate to its output: orbit loop, then the colour map
@@ -701,19 +705,23 @@ __global__ __launch_bounds__(64 * kWaves) void escape_kernel(const fr_kparams p,
  * coordinate per lane (`relevant` masks lanes whose column / row lies past the image edge and never
  * becomes a pixel) and returns the wave-uniform verdict. */
 template <typename T>
-__device__ __forceinline__ bool coords_admissible(const fr_kparams &p, double coord, bool relevant) {
+__device__ __forceinline__ bool coords_admissible(bool julia, double julia_re, double julia_im, double coord, bool relevant) {
     constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
     const T v = (T)coord;
     const T av = __builtin_fabs(v);
     const bool in_range = av >= lo && av <= hi;
     bool lane_ok;
-    if (p.algo == 2) {
-        const T jr = __builtin_fabs((T)p.julia_re), ji = __builtin_fabs((T)p.julia_im);
+    if (julia) {
+        const T jr = __builtin_fabs((T)julia_re), ji = __builtin_fabs((T)julia_im);
         lane_ok = (v == (T)0 || in_range) && jr >= lo && jr <= hi && ji >= lo && ji <= hi;
     } else {
         lane_ok = in_range;
     }
     return __ballot(relevant && !lane_ok) == 0ull;
+}
+template <typename T>
+__device__ __forceinline__ bool coords_admissible(const fr_kparams &p, double coord, bool relevant) {
+    return coords_admissible<T>(p.algo == 2, p.julia_re, p.julia_im, coord, relevant);
 }
 
 /* the strip kernel's layout: columns on lanes 0-55, the 8 rows on lanes 56-63 of one register */
@@ -1068,6 +1076,7 @@ hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipS
  * its lane, its wave or the order of patches. */
 constexpr uint32_t kQPatchW = 64, kQPatchH = 16, kQPatchPx = kQPatchW * kQPatchH;
 constexpr uint32_t kQStack = 128;
+constexpr uint32_t kQBatchDefault = 1; /* patches per counter increment (fr_kparams::queue_batch) */
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -1085,6 +1094,11 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     __shared__ T q_re[kQStack], q_im[kQStack];
     __shared__ uint32_t q_it[kQStack], q_px[kQStack], q_py[kQStack];
     extern __shared__ uint32_t s_dyn_palette[]; /* smooth == false: the palette, staged once */
+    /* Everything the two COLD phases need — opening a patch (once per 1024 pixels) and the colour pass (once
+     * per 64) — is RE-READ from the kernel-argument segment there (scalar loads through a pointer the
+     * optimiser cannot see through), instead of being held in SGPRs across the hot loop as kernel arguments
+     * normally are: those ~50 values overflow the scalar file and every use became a v_readlane spill reload. */
+    typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
     const uint32_t lane = threadIdx.x;
     const uint32_t *s_pal = nullptr;
     if (p.palette != nullptr) {
@@ -1093,13 +1107,19 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
         __syncthreads();
     }
     const double *tab = &g_log2_tab[0][0]; /* the exact colour path is rare here: the table stays in L2 */
-    const ColourConsts cc = make_colour_consts(p);
+    /* hot-path constants (SGPRs) */
     const bool julia = p.algo == 2;
     const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
     const T skip_t = (T)p.skip_t;
     const uint32_t cap = p.iterations;
-    const double width = (double)p.width, height = (double)p.height;
+    const uint32_t queue_want = p.queue_want, queue_minrun = p.queue_minrun;
+    const uint32_t qbatch = p.queue_batch ? p.queue_batch : kQBatchDefault;
     const T jre = (T)p.julia_re, jim = (T)p.julia_im;
+    uint32_t *const counter = p.work_counter;
+    /* `p` is the first kernel argument: offset 0 of the segment */
+#define FR_COLD_PARAMS(NAME)                                                          \
+    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();                       \
+    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay in this phase */
 
     /* per-lane orbit state: unscaled (re, im, re^2, im^2, c) or scaled (2re, 2im, X^2, Y^2, 2c) */
     T a0 = 0, a1 = 0, a2 = 0, a3 = 0, c0 = 0, c1 = 0;
@@ -1114,6 +1134,8 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     uint32_t held_id = 0;
     uint32_t next = 0, vw = 0, vh = 0, pcol0 = 0;
     uint32_t qcount = 0, upper = 0;
+    uint32_t batch_next = 0, batch_end = 0, pref = 0; /* patches in hand; the next batch's first id (lane 0) */
+    bool pref_valid = false;
     T hold_x = 0, hold_y = 0; /* coordinates of the held / just fetched patch: column `lane`, row `lane` */
     uint32_t hold_orow = 0;
 
@@ -1124,37 +1146,53 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
             if (!have_patch) {
                 if (!held) {
                     if (exhausted) break;
-                    uint32_t id = 0;
-                    if (lane == 0) id = atomicAdd(p.work_counter, 1u);
-                    id = __builtin_amdgcn_readfirstlane(id);
-                    if (id >= npatches) {
-                        exhausted = true;
-                        break;
+                    /* next patch: from the batch in hand, else from the counter — kQBatch patches per atomic
+                     * (7000 waves pulling single patches would saturate one word: ~88 dequeues/us), and the
+                     * NEXT batch is requested as soon as this one is opened, so its latency is never waited for */
+                    if (batch_next >= batch_end) {
+                        if (!pref_valid && lane == 0) pref = atomicAdd(counter, qbatch);
+                        const uint32_t start = __builtin_amdgcn_readfirstlane(pref);
+                        pref_valid = false;
+                        if (start >= npatches) {
+                            exhausted = true;
+                            break;
+                        }
+                        batch_next = start;
+                        batch_end = npatches - start < qbatch ? npatches : start + qbatch;
+                        if (lane == 0) pref = atomicAdd(counter, qbatch);
+                        pref_valid = true;
                     }
+                    const uint32_t id = batch_next++;
                     /* the patch's coordinate map (calc/src/lib.rs:182-197), one column and one row per lane */
+                    FR_COLD_PARAMS(kp);
+                    const auto &P = *kp;
                     const uint32_t pyi = id / npatch_x, pxi = id - pyi * npatch_x;
                     const uint32_t col = pxi * kQPatchW + lane, rr = pyi * kQPatchH + lane;
-                    const uint32_t x = p.x_first + col * p.x_stride;
-                    const uint32_t y = p.y_first + (rr / p.block_rows) * p.y_stride + rr % p.block_rows;
-                    const double cx = coord_to_space((double)x, height, (width / height) / 2.0, p.pos_re, p.scale_re);
-                    const double cy = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
+                    const uint32_t block_rows = P.block_rows;
+                    const uint32_t x = P.x_first + col * P.x_stride;
+                    const uint32_t y = P.y_first + (rr / block_rows) * P.y_stride + rr % block_rows;
+                    const double width = (double)P.width, height = (double)P.height;
+                    const double cx = coord_to_space((double)x, height, (width / height) / 2.0, P.pos_re, P.scale_re);
+                    const double cy = coord_to_space((double)y, height, 0.5, P.pos_im, P.scale_im);
                     hold_x = (T)cx;
                     hold_y = (T)cy;
-                    hold_orow = p.out_in_place ? y : rr;
+                    hold_orow = P.out_in_place ? y : rr;
                     held_id = id;
                     held_scaled = false;
-                    if constexpr (M != 0)
-                        held_scaled = coords_admissible<T>(p, cx, col < p.ncols) &&
-                                      coords_admissible<T>(p, cy, lane < kQPatchH && rr < p.nrows);
+                    if constexpr (M != 0) {
+                        const double pjre = P.julia_re, pjim = P.julia_im;
+                        held_scaled = coords_admissible<T>(julia, pjre, pjim, cx, col < P.ncols) &&
+                                      coords_admissible<T>(julia, pjre, pjim, cy, lane < kQPatchH && rr < P.nrows);
+                    }
                     held = true;
                 }
                 if (held_scaled != scaled && busy_mask != 0ull) break; /* drain first: one loop form per wave */
                 scaled = held_scaled;
                 const uint32_t pyi = held_id / npatch_x, pxi = held_id - pyi * npatch_x;
                 pcol0 = pxi * kQPatchW;
-                const uint32_t prow0 = pyi * kQPatchH;
-                vw = p.ncols - pcol0 < kQPatchW ? p.ncols - pcol0 : kQPatchW;
-                vh = p.nrows - prow0 < kQPatchH ? p.nrows - prow0 : kQPatchH;
+                const uint32_t prow0 = pyi * kQPatchH, ncols = p.ncols, nrows = p.nrows;
+                vw = ncols - pcol0 < kQPatchW ? ncols - pcol0 : kQPatchW;
+                vh = nrows - prow0 < kQPatchH ? nrows - prow0 : kQPatchH;
                 __syncthreads(); /* earlier reads of s_x / s_y are done */
                 s_x[lane] = hold_x;
                 if (lane < kQPatchH) {
@@ -1200,7 +1238,7 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
         EpisodeCtl ctl{0u, 0u};
         if (!(exhausted && !have_patch && !held) && !held) {
             /* more pixels are waiting: stop once `want` lanes have finished (and minrun iterations were done) */
-            ctl = EpisodeCtl{nbusy > p.queue_want ? nbusy - p.queue_want : 0u, p.queue_minrun};
+            ctl = EpisodeCtl{nbusy > queue_want ? nbusy - queue_want : 0u, queue_minrun};
         }
         uint32_t it = 0, completed = 0;
         if (busy) {
@@ -1245,8 +1283,10 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
                 const uint32_t e = qcount - 64u + lane;
                 const double zre = (double)q_re[e], zim = (double)q_im[e];
                 uint8_t rgb[3];
+                FR_COLD_PARAMS(kp);
+                const ColourConsts cc = make_colour_consts(*kp);
                 colour_of(cc, zre * zre + zim * zim, q_it[e], tab, s_pal, rgb); /* pos.squared_distance(), :214 */
-                store_pixel(p, out.rgb, q_py[e], q_px[e], rgb);
+                store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[e], q_px[e], rgb);
                 qcount -= 64u;
                 __syncthreads();
             }
@@ -1257,8 +1297,10 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     if (lane < qcount) {
         const double zre = (double)q_re[lane], zim = (double)q_im[lane];
         uint8_t rgb[3];
+        FR_COLD_PARAMS(kp);
+        const ColourConsts cc = make_colour_consts(*kp);
         colour_of(cc, zre * zre + zim * zim, q_it[lane], tab, s_pal, rgb);
-        store_pixel(p, out.rgb, q_py[lane], q_px[lane], rgb);
+        store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[lane], q_px[lane], rgb);
     }
 }
 
@@ -1267,7 +1309,7 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
     const uint64_t npx = ((uint64_t)p.ncols + kQPatchW - 1) / kQPatchW;
     const uint64_t npy = ((uint64_t)p.nrows + kQPatchH - 1) / kQPatchH;
     if (npx * npy == 0) return hipSuccess;
-    if (npx * npy > 0xFFFFFF00ull) return hipErrorInvalidConfiguration;
+    if (npx * npy > 0xFFF00000ull) return hipErrorInvalidConfiguration; /* the counter overshoots by <= 2 batches per wave */
     const size_t dyn = p.palette ? sizeof(uint32_t) * p.palette_entries : 0;
     /* persistent grid: as many one-wave workgroups as the device holds at once (asking for a few more
      * than that is harmless: a late workgroup finds the counter exhausted and leaves) */

@@ -233,6 +233,20 @@ int fr_multi_last_stats(fr_multi_stats *stats);
  * (loads librccl, creates the communicator) — the only RCCL traffic a one-GPU box can carry. */
 int fr_debug_rccl_selftest(size_t bytes);
 
+/* ---- get_image, Algo::BarnsleyFern arm — src/lib.rs:271-319, fern() :417-463 ------------------- */
+
+/* The chaos game on the GPU.  The reference gives every rayon thread an image filled with secondary_color
+ * and iterations / threads points (each point darkens the pixel it falls on: Image::subtract_pixel,
+ * src/lib.rs:383-401), then "reduces" the images with combine_images — which adds a into b and returns a
+ * (src/lib.rs:275-284, 305-316), so ONE thread's image comes back.  `threads` is that rayon thread count
+ * (>= 1).  The reference's RNG is seeded from entropy (src/lib.rs:428): its output is a sample of a
+ * distribution, and so is this one — drawn with Philox4x32-10 keyed by `seed` over `walkers` parallel
+ * orbits (0 = chosen from the point count).  Deterministic for a given (seed, walkers); bit-identical to the
+ * CPU restatement with the same RNG (oracle/); statistically a single sequential orbit (tests).
+ * fr_render_rgb8 itself keeps rendering BarnsleyFern BLACK, as calc::get_recursive_pixel does (:211). */
+int fr_render_fern_rgb8(const fr_config *cfg, uint32_t threads, uint64_t seed, uint32_t walkers, uint8_t *out,
+                        size_t out_len);
+
 /* ---- get_recursive_pixel — calc/src/lib.rs:199-235 ---------------------------------------- */
 
 int fr_pixel(const fr_config *cfg, uint32_t x, uint32_t y, fr_rgb *out);

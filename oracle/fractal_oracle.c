@@ -302,3 +302,103 @@ uint64_t fro_count_iterations_rows(const fro_config *cfg, int precision, uint32_
     }
     return total;
 }
+
+/* ---- Algo::BarnsleyFern: src/lib.rs:271-319 (get_image's fern arm), :369-401 (Image), :417-463 (fern) ----
+ *
+ * Restated with a deterministic RNG (the reference's SmallRng::from_entropy, :428, cannot be matched by
+ * anything, itself included): Philox4x32-10 keyed by `seed`, counter = (walker, step / 2, ...), two
+ * 53-bit uniforms per block, r = (u64 >> 11) * 2^-53 like rand's Standard f64.
+ *
+ * `walkers` == 1 is the reference's shape: ONE orbit of iterations / threads points from
+ * (pos.re * width, pos.im * height), every point plotted.  (get_image "reduces" the per-thread images with
+ * combine_images(a, b), which adds a INTO b and then returns a (:275-284, :305-316): the sum is dropped and
+ * the result is one thread's image — per_thread_iterations points, :286-287.)
+ * `walkers` > 1 cuts that orbit into pieces played independently: walker 0 as above, every other walker
+ * first takes 64 unplotted steps from the same start (it then sits on the attractor).  The image is built
+ * exactly as subtract_pixel builds it: pixel by pixel, hit by hit, in this restatement's own order (the
+ * result does not depend on the order: every hit applies the same function to the pixel it lands on). */
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+/* Rust `expr as usize` for an f64: saturating, NaN -> 0 */
+static uint64_t rust_f64_as_usize(double v) {
+    if (v != v || v <= 0.0) return 0;
+    if (v >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+
+/* Image::subtract_pixel — :383-401 (pixel_mut's bounds rules :376-382) */
+static void subtract_pixel(fro_rgb *contents, uint64_t width, uint64_t len, uint64_t x, uint64_t y, fro_rgb value,
+                           double amount) {
+    if (x > width) return; /* :377 (x == width is let through and lands on the next row) */
+    if (y > len) return;   /* y * width + x would exceed len (and could wrap) */
+    uint64_t index = y * width + x;
+    if (len < index) return; /* :381 */
+    if (index >= len) return; /* get_mut -> None */
+    fro_rgb *pixel = &contents[index];
+    *pixel = fro_rgb_new(
+        rust_f64_as_u8((double)pixel->r * 1.0 / ((((1.0 / ((double)value.r / 255.0)) - 1.0) * amount) + 1.0)),
+        rust_f64_as_u8((double)pixel->g * 1.0 / ((((1.0 / ((double)value.g / 255.0)) - 1.0) * amount) + 1.0)),
+        rust_f64_as_u8((double)pixel->b * 1.0 / ((((1.0 / ((double)value.b / 255.0)) - 1.0) * amount) + 1.0)));
+}
+
+int fro_fern_image(const fro_config *cfg, uint32_t threads, uint64_t seed, uint32_t walkers, uint8_t *out) {
+    const uint64_t w = cfg->width, h = cfg->height, len = w * h;
+    if (threads == 0 || walkers == 0 || len == 0) return -1;
+    fro_rgb *contents = (fro_rgb *)out; /* 3 packed bytes r, g, b: what the reference transmutes (:13-15) */
+    for (uint64_t k = 0; k < len; k++) contents[k] = cfg->secondary_color; /* :294-295 */
+    const uint64_t steps = cfg->iterations / threads;                      /* :286-287 */
+    const double width = (double)cfg->width, height = (double)cfg->height; /* :418-419 */
+    /* 0.006 just works fine — :424-425 */
+    const double effective_scale_x = 65.0 * cfg->scale.re * (double)cfg->height * 0.006;
+    const double effective_scale_y = 37.0 * cfg->scale.im * (double)cfg->height * 0.006;
+    const fro_rgb color = cfg->primary_color; /* :430 */
+    if ((uint64_t)walkers > steps) walkers = steps ? (uint32_t)steps : 1u;
+    for (uint32_t wk = 0; wk < walkers; wk++) {
+        const uint64_t n = steps / walkers + (wk < steps % walkers ? 1u : 0u);
+        const uint64_t burn = wk == 0 ? 0u : 64u;
+        double x = cfg->pos.re * width, y = cfg->pos.im * height; /* :420-421 */
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        for (uint64_t s = 0; s < n + burn; s++) {
+            if (s >= burn)
+                subtract_pixel(contents, w, len, rust_f64_as_usize(((x - cfg->pos.re) * effective_scale_x) + width / 2.0),
+                               rust_f64_as_usize(height - ((y + (cfg->pos.im - 5.0) - 0.5) * effective_scale_y + height / 2.0)),
+                               color, cfg->color_weight); /* :433-441 */
+            if ((s & 1) == 0) {
+                rnd[0] = wk, rnd[1] = (uint32_t)(s >> 1), rnd[2] = (uint32_t)(s >> 33), rnd[3] = 0;
+                philox4x32_10(rnd, (uint32_t)seed, (uint32_t)(seed >> 32));
+            }
+            uint64_t bits = ((uint64_t)rnd[(s & 1) * 2 + 1] << 32) | rnd[(s & 1) * 2];
+            double r = (double)(bits >> 11) * 0x1p-53; /* :443 `rng.gen::<f64>()` */
+            /* :446-461 */
+            if (r < 0.01) {
+                double old_x = x;
+                x = 0.00 * x + 0.00 * y;
+                y = 0.00 * old_x + 0.16 * y + 0.00;
+            } else if (r < 0.86) {
+                double old_x = x;
+                x = 0.85 * x + 0.04 * y;
+                y = -0.04 * old_x + 0.85 * y + 1.60;
+            } else if (r < 0.93) {
+                double old_x = x;
+                x = 0.20 * x - 0.26 * y;
+                y = 0.23 * old_x + 0.22 * y + 1.60;
+            } else {
+                double old_x = x;
+                x = -0.15 * x + 0.28 * y;
+                y = 0.26 * old_x + 0.24 * y + 0.44;
+            }
+        }
+        (void)h;
+    }
+    return 0;
+}

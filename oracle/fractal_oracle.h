@@ -118,6 +118,12 @@ uint64_t fro_count_iterations_rows(const fro_config *cfg, int precision, uint32_
 /* the log2 currently selected, exposed for ulp studies in tests */
 double fro_log2(double x);
 
+/* Algo::BarnsleyFern — src/lib.rs:271-319, 369-401, 417-463 with a deterministic RNG (Philox4x32-10 keyed by
+ * `seed`).  threads = rayon::current_num_threads() of the machine being modelled; walkers == 1 is the
+ * reference's single sequential orbit, > 1 the same orbit cut into independently played pieces.  Writes
+ * 3 * width * height bytes r, g, b.  Returns 0, or -1 on a degenerate argument. */
+int fro_fern_image(const fro_config *cfg, uint32_t threads, uint64_t seed, uint32_t walkers, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

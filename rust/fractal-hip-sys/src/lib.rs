@@ -64,6 +64,11 @@ extern "C" {
     pub fn fr_pixel(cfg: *const fr_config, x: u32, y: u32, out: *mut fr_rgb) -> c_int;
     pub fn fr_recursive(iterations: u32, start: fr_imaginary, c: fr_imaginary, limit: f64, out_pos: *mut fr_imaginary, out_iters: *mut u32) -> c_int;
     pub fn fr_escape_rows(cfg: *const fr_config, precision: c_int, y0: u32, y1: u32, z_re_im: *mut f64, iters: *mut u32) -> c_int;
+    // one process, several GPUs (include/fractal_hip.h, "get_image across several GPUs from ONE process")
+    pub fn fr_init_devices(devices: *const c_int, n: c_int) -> c_int;
+    pub fn fr_render_rgb8_multi(cfg: *const fr_config, precision: c_int, block_rows: u32, out: *mut u8, out_len: usize) -> c_int;
+    // Algo::BarnsleyFern (src/lib.rs:271-319, 417-463) on the GPU
+    pub fn fr_render_fern_rgb8(cfg: *const fr_config, threads: u32, seed: u64, walkers: u32, out: *mut u8, out_len: usize) -> c_int;
 }
 
 /// Message of the last failing call on this thread.
@@ -74,6 +79,14 @@ pub fn last_error() -> String {
     }
 }
 
+/// Select the GPUs `render_into` spreads an image over (row-block-cyclically, one host thread and one
+/// PCIe link per GPU).  Not calling it, or passing one device, renders on a single GPU.
+pub fn use_devices(devices: &[c_int]) -> Result<(), String> {
+    let rc = unsafe { fr_init_devices(devices.as_ptr(), devices.len() as c_int) };
+    if rc != FR_OK { Err(last_error()) } else { MULTI.store(devices.len() > 1, std::sync::atomic::Ordering::Relaxed); Ok(()) }
+}
+static MULTI: std::sync::atomic::AtomicBool = std::sync::atomic::AtomicBool::new(false);
+
 /// `get_image` for `Algo::Mandelbrot | Algo::Julia` (src/lib.rs:253-270): fills a caller-owned
 /// pixel vector in place.  `P` must be a 3-byte `#[repr(C)]` pixel (`calc::RGB` once annotated).
 pub fn render_into<P: Copy>(cfg: &fr_config, image: &mut Vec<P>) -> Result<(), String> {
@@ -81,10 +94,31 @@ pub fn render_into<P: Copy>(cfg: &fr_config, image: &mut Vec<P>) -> Result<(), S
     let n = cfg.width as usize * cfg.height as usize;
     image.clear();
     image.reserve_exact(n);
-    let rc = unsafe { fr_render_rgb8(cfg, image.as_mut_ptr() as *mut u8, n * 3) };
+    let out = image.as_mut_ptr() as *mut u8;
+    let rc = if MULTI.load(std::sync::atomic::Ordering::Relaxed) {
+        unsafe { fr_render_rgb8_multi(cfg, FR_PRECISION_F64, 0, out, n * 3) }
+    } else {
+        unsafe { fr_render_rgb8(cfg, out, n * 3) }
+    };
     if rc != FR_OK {
         return Err(last_error());
     }
     unsafe { image.set_len(n) }; // every byte was written by the library
+    Ok(())
+}
+
+/// `get_image`'s `Algo::BarnsleyFern` arm (src/lib.rs:271-319): `threads` is what
+/// `rayon::current_num_threads()` returns on this machine (the reference's result is ONE thread's image of
+/// `iterations / threads` points), `seed` replaces `SmallRng::from_entropy()` (src/lib.rs:428).
+pub fn fern_into<P: Copy>(cfg: &fr_config, threads: u32, seed: u64, image: &mut Vec<P>) -> Result<(), String> {
+    assert_eq!(std::mem::size_of::<P>(), 3, "pixel type must be 3 packed bytes");
+    let n = cfg.width as usize * cfg.height as usize;
+    image.clear();
+    image.reserve_exact(n);
+    let rc = unsafe { fr_render_fern_rgb8(cfg, threads, seed, 0, image.as_mut_ptr() as *mut u8, n * 3) };
+    if rc != FR_OK {
+        return Err(last_error());
+    }
+    unsafe { image.set_len(n) };
     Ok(())
 }

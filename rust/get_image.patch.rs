@@ -5,7 +5,11 @@
 //     pub struct RGB { pub r: u8, pub g: u8, pub b: u8 }
 //
 // src/lib.rs:253-270 — the Mandelbrot | Julia arm of get_image becomes one FFI call; the
-// BarnsleyFern arm (src/lib.rs:271-319) is untouched.
+// BarnsleyFern arm (src/lib.rs:271-319) either stays as it is or becomes one too (`fern_into`: same
+// distribution, a seeded RNG instead of SmallRng::from_entropy).
+//
+// src/main.rs — once, before the first render, to spread images over every GPU of the node:
+//     fractal_hip_sys::use_devices(&[0, 1, 2, 3, 4, 5, 6, 7]).expect("fractal_hip");
 
 fn to_ffi(config: &Config) -> fractal_hip_sys::fr_config {
     use fractal_hip_sys::{fr_config, fr_imaginary, fr_rgb};
@@ -40,6 +44,13 @@ pub fn get_image(config: &Config) -> Vec<RGB> {
                 .unwrap_or_else(|e| panic!("fractal_hip: {}", e));
             image
         }
-        Algo::BarnsleyFern => { /* src/lib.rs:271-319 unchanged */ unimplemented!() }
+        Algo::BarnsleyFern => {
+            // either keep the body of src/lib.rs:271-319 here unchanged, or:
+            let mut image: Vec<RGB> = Vec::new();
+            let seed = rand::random::<u64>(); // the reference seeds from entropy too (src/lib.rs:428)
+            fractal_hip_sys::fern_into(&to_ffi(config), rayon::current_num_threads() as u32, seed, &mut image)
+                .unwrap_or_else(|e| panic!("fractal_hip: {}", e));
+            image
+        }
     }
 }

@@ -93,6 +93,8 @@ def lib():
     L.fro_get_log2_mode.restype = C.c_int
     L.fro_log2.restype = C.c_double
     L.fro_log2.argtypes = [C.c_double]
+    L.fro_fern_image.restype = C.c_int
+    L.fro_fern_image.argtypes = [C.POINTER(Config), C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -178,3 +180,12 @@ def set_log2_mode(mode):
 
 def log2(x):
     return lib().fro_log2(x)
+
+
+def fern_image(cfg, threads=1, seed=0, walkers=1):
+    """get_image's BarnsleyFern arm (src/lib.rs:271-319, 417-463) with the deterministic RNG; walkers == 1 is
+    the reference's single sequential orbit."""
+    out = np.empty((cfg.height, cfg.width, 3), dtype=np.uint8)
+    if lib().fro_fern_image(C.byref(cfg), threads, seed, walkers, out.ctypes.data) != 0:
+        raise ValueError("degenerate fern arguments")
+    return out
