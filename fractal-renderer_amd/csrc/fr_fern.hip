@@ -25,9 +25,9 @@
  *      steps: channels shrink to 0, or are untouched when the matching primary channel is 255) and the
  *      device maps count -> colour through that table.
  * Random numbers: Philox4x32-10 keyed by `seed`, counter = (walker, step / 2), two 53-bit uniforms per block —
- * build-defined, deterministic, and restated independently in oracle/fractal_oracle.c, against which the
+ * build-defined, deterministic, and restated independently by the test oracle (oracle/), against which the
  * device result is BIT-exact (same seed, same walkers); the match with a single sequential orbit, the
- * reference's shape, is statistical (tests/test_gpu_fern.py).
+ * reference's shape, is statistical (tests/test_fern.py).
  */
 #include <cmath>
 #include <cstring>
