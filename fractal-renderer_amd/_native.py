@@ -197,6 +197,7 @@ PROTOTYPES = {
     "fr_set_cycle_shortcut": (C.c_int, [C.c_int]),
     "fr_set_refill_policy": (C.c_int, [C.c_int, C.c_int]),
     "fr_debug_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fr_debug_set_queue_trace": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

@@ -50,6 +50,7 @@ std::atomic<int> g_cycle_shortcut{0};
 std::atomic<int> g_refill_minrun{-1}, g_refill_quit16{-1}; /* -1: each kernel's own default */
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 std::atomic<int> g_colour_filter{1};
+std::atomic<unsigned long long *> g_queue_trace{nullptr}; /* tuning aid, see fr_debug_set_queue_trace */
 
 bool valid_tile(int tile) {
     switch (tile) {
@@ -307,11 +308,11 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
     p.queue_minrun = o.refill_minrun < 0 ? 8u : (uint32_t)o.refill_minrun;
     p.queue_want = o.refill_quit16 < 0 ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
-    static const uint32_t env_batch = [] {
-        const char *e = getenv("FR_QUEUE_BATCH"); /* tuning studies only */
+    static const uint32_t env_flags = [] {
+        const char *e = getenv("FR_DEBUG_FLAGS"); /* tuning experiments only; results are then NOT images */
         return e ? (uint32_t)atoi(e) : 0u;
     }();
-    p.queue_batch = env_batch;
+    p.debug_flags = env_flags;
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
     /* the colour filter's constants (fr_kernels.hip: colour_outside_filtered) and the conditions under
@@ -445,6 +446,7 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
     } guard{ctx, slot, stream};
     fr_kout out{};
     out.rgb = static_cast<uint8_t *>(d_out);
+    out.trace = g_queue_trace.load();
     Profiling &pr = tl_prof;
     if (pr.enabled) {
         if (!pr.e0) {
@@ -987,6 +989,13 @@ int fr_set_loop_mode(int mode) {
     if (mode != -1 && mode != 0 && mode != 2 && mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "loop mode must be -1 (auto), 0, 2 or 4");
     g_loop_mode.store(mode);
+    return FR_OK;
+}
+
+/* tuning aid: device buffer (8 u64 per persistent wave, >= 64 KiB x 8) the work-queue kernel's waves write
+ * their start / end time and work counts to; NULL = off */
+int fr_debug_set_queue_trace(void *d_trace) {
+    g_queue_trace.store(static_cast<unsigned long long *>(d_trace));
     return FR_OK;
 }
 

@@ -53,7 +53,7 @@ struct fr_kparams {
     /* work-queue kernel: while more pixels wait, an episode ends once `queue_want` lanes have finished and
      * `queue_minrun` iterations were done */
     uint32_t queue_minrun, queue_want;
-    uint32_t queue_batch; /* patches per counter increment; 0 = the kernel's default (tuning: FR_QUEUE_BATCH) */
+    uint32_t debug_flags; /* tuning experiments (FR_DEBUG_FLAGS): 1 = the work-queue kernel skips its pixel stores */
     /* exact periodicity shortcut (refilling kernel, scaled loops): an orbit found bitwise back at an
      * earlier state is fast-forwarded to the cap instead of being iterated there; 0 = off */
     uint32_t cycle_shortcut;
@@ -84,6 +84,9 @@ struct fr_kout {
     double *z;
     uint32_t *iters;
     unsigned long long *count;
+    /* tuning aid (fr_debug_set_queue_trace): the work-queue kernel's waves record 8 words each here —
+     * start, end (100 MHz realtime ticks), patches opened, episodes, colour passes, iterations run, 0, 0 */
+    unsigned long long *trace;
 };
 
 /* tile = kernel-variant selector (see fr_set_tile in include/fractal_hip.h); 0 = default.

@@ -1056,27 +1056,32 @@ hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipS
 /* ---- work-queue kernel ----------------------------------------------------------------------------
  *
  * For views whose orbits are mostly short with a heavy tail (Julia sets: C4's mean is 44 iterations at a
- * cap of 4096), the strip kernel idles two thirds of its lanes and the patch-refill kernel above still
- * pays (a) a tail of idle lanes at the end of every 896-pixel patch, (b) a full f64 colour pass — under a
- * partial EXEC mask — after every episode, and (c) ~60 instructions of bookkeeping per episode.
- * Here:
- *   - waves are PERSISTENT and draw 64 x 16-pixel patches from a device-wide atomic counter: a lane's
- *     pixel outlives its patch, so the only tail is the one at the very end of the image;
- *   - a finished lane pushes (re, im, escape index, output position) onto a per-wave LDS stack and takes
- *     the next pixel; the colour map + store runs only when 64 results are waiting — always a FULL wave;
- *   - a patch's column / row coordinates (calc/src/lib.rs:181-197: 2 IEEE divisions per column and per
- *     row, not per pixel) are staged in LDS when the patch is opened, so handing a lane its next pixel is
- *     two LDS reads and two multiplies;
- *   - the per-lane iteration cap is enforced with one compare per episode; the episode length comes from a
- *     wave-uniform upper bound of the lanes' counts that is re-derived (a wave reduction) only when it
- *     reaches the cap.
- * The scaled loops need every lane of the wave admissible (see "orbit loop, scaled form"); a patch that
- * is not (it contains the im == 0 row or the re == 0 column) is opened only after the wave has drained,
- * and runs the unscaled loop.  Results are independent of the schedule: a pixel's orbit never depends on
- * its lane, its wave or the order of patches. */
-constexpr uint32_t kQPatchW = 64, kQPatchH = 16, kQPatchPx = kQPatchW * kQPatchH;
+ * cap of 4096).  There the strip kernel idles two thirds of its lanes, and in the patch-refill kernel
+ * above some lane of every wave is always on its way out (with ~1.5 escapes per wave-iteration, a few
+ * lanes are permanently between T and limit^2), so the wave never leaves the loop's fully-checked path:
+ * 8 VALU + an EXEC-bookkeeping branch per iteration instead of 6.5, plus a partial-EXEC colour pass after
+ * every episode.  This kernel separates the two regimes:
+ *
+ *   main loop      blocks of M unchecked iterations of the scaled form (6 VALU each), then ONE test per
+ *                  block: |z|^2 <= T?  A lane that fails it freezes (v_cmpx) — by the choice of T
+ *                  (fr_api.hip: plan_loop) it cannot have escaped before the block's last iteration — and
+ *                  is pushed, UNFINISHED, onto a per-wave LDS stack: position, c, iterations done, pixel.
+ *                  A per-lane f32 counter (+M per block, frozen with the lane) replaces every escape-index
+ *                  handler.  27 VALU per 4 iterations, whatever the lanes are doing.
+ *   finishing pass when 64 results wait: a FULL wave runs the last few iterations of each with the exact
+ *                  per-iteration check (the unscaled loop; a pixel past T is 4-5 iterations from limit^2),
+ *                  then the colour map and the store.  Pixels that may not use the scaled form at all
+ *                  (the im == 0 row, the re == 0 column) and lanes within M iterations of the cap take the
+ *                  same road with their whole remaining orbit.
+ *   persistent     waves draw 64 x 16-pixel patches from a device-wide counter (one ahead, so the atomic's
+ *                  latency is never waited for): a lane's pixel outlives its patch and the only tail is
+ *                  the one at the end of the image.  A patch's column / row coordinates
+ *                  (calc/src/lib.rs:181-197: two IEEE divisions per column and per row, not per pixel) are
+ *                  staged in LDS when it is opened; a refill is two LDS reads and two multiplies.
+ * Results are independent of the schedule: a pixel's orbit never depends on its lane, its wave, the order
+ * of patches or where the main loop hands it over. */
+constexpr uint32_t kQPatchW = 64, kQPatchH = 16;
 constexpr uint32_t kQStack = 128;
-constexpr uint32_t kQBatchDefault = 1; /* patches per counter increment (fr_kparams::queue_batch) */
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -1086,19 +1091,87 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+/* One run of the main loop: blocks of M unchecked scaled iterations, one |z|^2 <= T test per block.
+ * In: the active lanes (EXEC) all have A + B <= 4T.  Out: `running` = the lanes that passed every test
+ * (the others froze at the end of the block whose test they failed), `cnt` += M per block while running,
+ * return value = blocks done.  Ends when no lane runs, after `n` blocks, or — once `minrun` blocks were done —
+ * when at most `thr` lanes still run. */
+#define FR_QB_ASM(SFX, BLOCK_ITS, STEP)                                            \
+    "s_mov_b64 %[sorig], exec\n"                                                   \
+    "s_mov_b32 %[si], 0\n"                                                         \
+    "s_cbranch_execz .Lqdone_%=\n"                                                 \
+    ".Lqloop_%=:\n" BLOCK_ITS                                                      \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                                             \
+    "v_add_f32 %[cnt], %[cnt], " STEP "\n"                                         \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"                                          \
+    "s_add_u32 %[si], %[si], 1\n"                                                  \
+    "s_cbranch_execz .Lqdone_%=\n"                                                 \
+    "s_bcnt1_i32_b64 %[scnt], exec\n"                                              \
+    "s_cmp_gt_u32 %[scnt], %[thr]\n"                                               \
+    "s_cbranch_scc0 .Lqmaybe_%=\n"                                                 \
+    ".Lqcont_%=:\n"                                                                \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc1 .Lqloop_%=\n"                                                  \
+    "s_branch .Lqdone_%=\n"                                                        \
+    ".Lqmaybe_%=:\n"                                                               \
+    "s_cmp_lt_u32 %[si], %[minrun]\n"                                              \
+    "s_cbranch_scc1 .Lqcont_%=\n"                                                  \
+    ".Lqdone_%=:\n"                                                                \
+    "s_mov_b64 %[srun], exec\n"                                                    \
+    "s_mov_b64 exec, %[sorig]\n"
+
+template <typename T, int M>
+__device__ __forceinline__ uint32_t queue_block_run(uint32_t nblocks, T &X, T &Y, T &A, T &B, T c2re, T c2im, T skip_t,
+                                                    float &cnt, uint32_t thr, uint32_t minrun, unsigned long long &running) {
+    T t;
+    T q;
+    unsigned long long sorig, srun;
+    uint32_t si, scnt;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(nblocks);
+    const uint32_t sthr = __builtin_amdgcn_readfirstlane(thr), smin = __builtin_amdgcn_readfirstlane(minrun);
+    const T t4_v = (T)4 * skip_t;
+#define FR_QB_OPERANDS                                                                                          \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [cnt] "+v"(cnt), [t] "=&v"(t), [q] "=&v"(q),          \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [si] "=&s"(si), [scnt] "=&s"(scnt)                              \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [n] "s"(n), [thr] "s"(sthr), [minrun] "s"(smin)   \
+    : "vcc", "scc"
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t tb = fr_bits_of(t4_v);
+        const uint64_t t4lim = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)tb) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32);
+        if constexpr (M == 4)
+            asm volatile(FR_QB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_QB_OPERANDS);
+        else
+            asm volatile(FR_QB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "2.0") FR_QB_OPERANDS);
+    } else {
+        const uint32_t t4lim = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, t4_v));
+        if constexpr (M == 4)
+            asm volatile(FR_QB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_QB_OPERANDS);
+        else
+            asm volatile(FR_QB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_QB_OPERANDS);
+    }
+    running = srun;
+    return si;
+}
+
 template <typename T, int M>
 __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, const fr_kout out, uint32_t npatch_x,
                                                           uint32_t npatches) {
+    static_assert(M == 4 || M == 2, "the main loop is the scaled form in blocks of M");
     __shared__ T s_x[kQPatchW], s_y[kQPatchH];
     __shared__ uint32_t s_orow[kQPatchH];
-    __shared__ T q_re[kQStack], q_im[kQStack];
+    /* the stack of unfinished results: position and c (unscaled), iterations done, output position */
+    __shared__ T q_re[kQStack], q_im[kQStack], q_cre[kQStack], q_cim[kQStack];
     __shared__ uint32_t q_it[kQStack], q_px[kQStack], q_py[kQStack];
     extern __shared__ uint32_t s_dyn_palette[]; /* smooth == false: the palette, staged once */
-    /* Everything the two COLD phases need — opening a patch (once per 1024 pixels) and the colour pass (once
+    /* Everything the COLD phases need — opening a patch (once per 1024 pixels) and the colour pass (once
      * per 64) — is RE-READ from the kernel-argument segment there (scalar loads through a pointer the
      * optimiser cannot see through), instead of being held in SGPRs across the hot loop as kernel arguments
      * normally are: those ~50 values overflow the scalar file and every use became a v_readlane spill reload. */
     typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
+#define FR_COLD_PARAMS(NAME)                                                          \
+    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is argument 0 */ \
+    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay in this phase */
     const uint32_t lane = threadIdx.x;
     const uint32_t *s_pal = nullptr;
     if (p.palette != nullptr) {
@@ -1110,198 +1183,206 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     /* hot-path constants (SGPRs) */
     const bool julia = p.algo == 2;
     const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
-    const T skip_t = (T)p.skip_t;
+    const T skip_t = (T)p.skip_t, t4 = (T)4 * (T)p.skip_t;
     const uint32_t cap = p.iterations;
-    const uint32_t queue_want = p.queue_want, queue_minrun = p.queue_minrun;
-    const uint32_t qbatch = p.queue_batch ? p.queue_batch : kQBatchDefault;
+    const uint32_t queue_want = p.queue_want, queue_minblocks = (p.queue_minrun + M - 1) / M;
     const T jre = (T)p.julia_re, jim = (T)p.julia_im;
     uint32_t *const counter = p.work_counter;
-    /* `p` is the first kernel argument: offset 0 of the segment */
-#define FR_COLD_PARAMS(NAME)                                                          \
-    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();                       \
-    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay in this phase */
+    const bool tracing = out.trace != nullptr;
+    const unsigned long long t_start = tracing ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t tr_patches = 0, tr_episodes = 0, tr_colour = 0, tr_iters = 0;
+    unsigned long long ph_open = 0, ph_refill = 0, ph_loop = 0, ph_retire = 0, ph_finish = 0, ph_mark = 0;
+#define FR_PHASE_BEGIN() if (tracing) ph_mark = __builtin_amdgcn_s_memtime()
+#define FR_PHASE_END(ACC) if (tracing) ACC += __builtin_amdgcn_s_memtime() - ph_mark
 
-    /* per-lane orbit state: unscaled (re, im, re^2, im^2, c) or scaled (2re, 2im, X^2, Y^2, 2c) */
-    T a0 = 0, a1 = 0, a2 = 0, a3 = 0, c0 = 0, c1 = 0;
-    uint32_t done = 0, px = 0, py = 0;
+    /* per-lane state of a running orbit: X = 2re, Y = 2im, A = X^2, B = Y^2, 2c; iterations done (exact in f32:
+     * the host sends caps >= 2^24 elsewhere); where the pixel goes */
+    T X = 0, Y = 0, A = 0, B = 0, c2re = 0, c2im = 0;
+    float cnt = 0.0f;
+    uint32_t px = 0, py = 0;
     bool busy = false;
     /* wave-uniform state */
-    bool scaled = M != 0;      /* loop form of the lanes now running */
-    bool have_patch = false;   /* s_x / s_y hold a patch with unstarted pixels */
-    bool exhausted = false;    /* the counter ran past the last patch */
-    bool held = false;         /* a fetched patch waits for the wave to drain (its loop form differs) */
-    bool held_scaled = false;
-    uint32_t held_id = 0;
-    uint32_t next = 0, vw = 0, vh = 0, pcol0 = 0;
-    uint32_t qcount = 0, upper = 0;
-    uint32_t batch_next = 0, batch_end = 0, pref = 0; /* patches in hand; the next batch's first id (lane 0) */
-    bool pref_valid = false;
-    T hold_x = 0, hold_y = 0; /* coordinates of the held / just fetched patch: column `lane`, row `lane` */
-    uint32_t hold_orow = 0;
+    uint32_t have_patch = 0, exhausted = 0, next = 0, vw = 0, vh = 0, pcol0 = 0;
+    uint32_t qcount = 0, upper = 0; /* results waiting; upper bound of the running lanes' iteration counts */
+    uint32_t pref = 0;              /* lane 0: the id of the next patch (requested one patch ahead) */
+    if (lane == 0) pref = atomicAdd(counter, 1u);
 
-    while (true) {
-        /* ---- hand unstarted pixels to the free lanes, opening patches as needed */
-        unsigned long long busy_mask = __ballot(busy);
-        while (busy_mask != ~0ull) {
-            if (!have_patch) {
-                if (!held) {
-                    if (exhausted) break;
-                    /* next patch: from the batch in hand, else from the counter — kQBatch patches per atomic
-                     * (7000 waves pulling single patches would saturate one word: ~88 dequeues/us), and the
-                     * NEXT batch is requested as soon as this one is opened, so its latency is never waited for */
-                    if (batch_next >= batch_end) {
-                        if (!pref_valid && lane == 0) pref = atomicAdd(counter, qbatch);
-                        const uint32_t start = __builtin_amdgcn_readfirstlane(pref);
-                        pref_valid = false;
-                        if (start >= npatches) {
-                            exhausted = true;
-                            break;
-                        }
-                        batch_next = start;
-                        batch_end = npatches - start < qbatch ? npatches : start + qbatch;
-                        if (lane == 0) pref = atomicAdd(counter, qbatch);
-                        pref_valid = true;
+    /* the finishing pass over the top 64 (or, at the end, all remaining) stack entries */
+    auto finish_and_colour = [&](uint32_t base, uint32_t count) {
+        const unsigned long long f0 = tracing ? __builtin_amdgcn_s_memtime() : 0ull;
+        __syncthreads();
+        const bool mine = lane < count;
+        const uint32_t e = base + (mine ? lane : 0u);
+        T re = q_re[e], im = q_im[e];
+        const T cre = q_cre[e], cim = q_cim[e];
+        uint32_t done = q_it[e];
+        T r2 = re * re, i2 = im * im;
+        /* did the last iteration it ran escape?  (the earlier ones of its block cannot have: see plan_loop;
+         * a fresh pixel, done == 0, has not been tested yet: recursive() tests AFTER an iteration) */
+        const bool escaped0 = mine && done > 0u && r2 + i2 > squared; /* NaN: false, as in the reference */
+        bool live = mine && !escaped0 && done < cap;
+        uint32_t iters = escaped0 ? done - 1u : cap;
+        /* exact per-iteration checks for whoever is not finished: the unscaled loop, as many rounds as the
+         * lanes' different distances to the cap need (one, unless a lane is about to hit the cap) */
+        while (__ballot(live) != 0ull) {
+            const uint32_t n = wave_min_u32(live ? cap - done : 0xFFFFFFFFu);
+            uint32_t it = 0, completed = 0;
+            if (live) it = orbit_run<T>(n, re, im, cre, cim, squared, r2, i2, EpisodeCtl{0u, 0u}, completed);
+            if (live) {
+                if (it < completed) { /* escaped at index it of this run */
+                    iters = done + it;
+                    live = false;
+                } else {
+                    done += completed;
+                    if (done >= cap) {
+                        iters = cap;
+                        live = false;
                     }
-                    const uint32_t id = batch_next++;
-                    /* the patch's coordinate map (calc/src/lib.rs:182-197), one column and one row per lane */
-                    FR_COLD_PARAMS(kp);
-                    const auto &P = *kp;
-                    const uint32_t pyi = id / npatch_x, pxi = id - pyi * npatch_x;
-                    const uint32_t col = pxi * kQPatchW + lane, rr = pyi * kQPatchH + lane;
-                    const uint32_t block_rows = P.block_rows;
-                    const uint32_t x = P.x_first + col * P.x_stride;
-                    const uint32_t y = P.y_first + (rr / block_rows) * P.y_stride + rr % block_rows;
-                    const double width = (double)P.width, height = (double)P.height;
-                    const double cx = coord_to_space((double)x, height, (width / height) / 2.0, P.pos_re, P.scale_re);
-                    const double cy = coord_to_space((double)y, height, 0.5, P.pos_im, P.scale_im);
-                    hold_x = (T)cx;
-                    hold_y = (T)cy;
-                    hold_orow = P.out_in_place ? y : rr;
-                    held_id = id;
-                    held_scaled = false;
-                    if constexpr (M != 0) {
-                        const double pjre = P.julia_re, pjim = P.julia_im;
-                        held_scaled = coords_admissible<T>(julia, pjre, pjim, cx, col < P.ncols) &&
-                                      coords_admissible<T>(julia, pjre, pjim, cy, lane < kQPatchH && rr < P.nrows);
-                    }
-                    held = true;
                 }
-                if (held_scaled != scaled && busy_mask != 0ull) break; /* drain first: one loop form per wave */
-                scaled = held_scaled;
-                const uint32_t pyi = held_id / npatch_x, pxi = held_id - pyi * npatch_x;
+            }
+        }
+        if (mine) {
+            FR_COLD_PARAMS(kp);
+            const ColourConsts cc = make_colour_consts(*kp);
+            const double zre = (double)re, zim = (double)im;
+            const double dist = sizeof(T) == 8 ? (double)(r2 + i2) : zre * zre + zim * zim; /* pos.squared_distance(), :214 */
+            uint8_t rgb[3];
+            colour_of(cc, dist, iters, tab, s_pal, rgb);
+            if (!(kp->debug_flags & 1u) || rgb[0] == 77) /* experiment: what do the stores cost? */
+                store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[e], q_px[e], rgb);
+        }
+        tr_colour++;
+        __syncthreads();
+        if (tracing) ph_finish += __builtin_amdgcn_s_memtime() - f0;
+    };
+    /* push the lanes with `who` set; re/im/c are the UNSCALED values */
+    auto push = [&](bool who, T re, T im, T cre, T cim, uint32_t done) {
+        const unsigned long long m = __ballot(who);
+        if (m == 0ull) return;
+        if (who) {
+            const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            q_re[slot] = re, q_im[slot] = im, q_cre[slot] = cre, q_cim[slot] = cim;
+            q_it[slot] = done, q_px[slot] = px, q_py[slot] = py;
+        }
+        qcount += (uint32_t)__builtin_popcountll(m);
+        if (qcount >= 64u) {
+            finish_and_colour(qcount - 64u, 64u);
+            qcount -= 64u;
+        }
+    };
+
+    for (;;) {
+        /* ---- 1. open the next patch when the current one is used up */
+        FR_PHASE_BEGIN();
+        if (!have_patch && !exhausted) {
+            const uint32_t id = __builtin_amdgcn_readfirstlane(pref);
+            if (id >= npatches) {
+                exhausted = 1;
+            } else {
+                if (lane == 0) pref = atomicAdd(counter, 1u); /* its answer is needed one patch from now */
+                FR_COLD_PARAMS(kp);
+                const auto &P = *kp;
+                /* the patch's coordinate map (calc/src/lib.rs:182-197), one column and one row per lane */
+                const uint32_t pyi = id / npatch_x, pxi = id - pyi * npatch_x;
+                const uint32_t col = pxi * kQPatchW + lane, rr = pyi * kQPatchH + lane;
+                const uint32_t block_rows = P.block_rows;
+                const uint32_t x = P.x_first + col * P.x_stride;
+                const uint32_t y = P.y_first + (rr / block_rows) * P.y_stride + rr % block_rows;
+                const double width = (double)P.width, height = (double)P.height;
+                const double cx = coord_to_space((double)x, height, (width / height) / 2.0, P.pos_re, P.scale_re);
+                const double cy = coord_to_space((double)y, height, 0.5, P.pos_im, P.scale_im);
+                const uint32_t ncols = P.ncols, nrows = P.nrows, prow0 = pyi * kQPatchH;
                 pcol0 = pxi * kQPatchW;
-                const uint32_t prow0 = pyi * kQPatchH, ncols = p.ncols, nrows = p.nrows;
                 vw = ncols - pcol0 < kQPatchW ? ncols - pcol0 : kQPatchW;
                 vh = nrows - prow0 < kQPatchH ? nrows - prow0 : kQPatchH;
                 __syncthreads(); /* earlier reads of s_x / s_y are done */
-                s_x[lane] = hold_x;
+                s_x[lane] = (T)cx;
                 if (lane < kQPatchH) {
-                    s_y[lane] = hold_y;
-                    s_orow[lane] = hold_orow;
+                    s_y[lane] = (T)cy;
+                    s_orow[lane] = P.out_in_place ? y : rr;
                 }
                 __syncthreads();
-                held = false;
-                have_patch = true;
+                have_patch = 1;
                 next = 0;
+                tr_patches++;
             }
+        }
+        FR_PHASE_END(ph_open);
+        /* ---- 2. hand unstarted pixels to the free lanes */
+        FR_PHASE_BEGIN();
+        unsigned long long busy_mask = __ballot(busy);
+        if (have_patch && busy_mask != ~0ull) {
             const unsigned long long free_mask = ~busy_mask;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
             const uint32_t pix = next + rank;
             const uint32_t col = pix & (kQPatchW - 1), row = pix >> 6;
-            if (!busy && pix < kQPatchPx && col < vw && row < vh) {
-                const T sx = s_x[col], sy = s_y[row];
-                const T cre = julia ? jre : sx, cim = julia ? jim : sy; /* calc/src/lib.rs:209-210 */
-                if (scaled) {
-                    a0 = sx + sx, a1 = sy + sy, a2 = a0 * a0, a3 = a1 * a1, c0 = cre + cre, c1 = cim + cim;
-                } else {
-                    a0 = sx, a1 = sy, a2 = sx * sx, a3 = sy * sy, c0 = cre, c1 = cim;
-                }
+            bool direct = false; /* this pixel cannot enter the main loop: straight to the finishing pass */
+            T sx = 0, sy = 0, cre = 0, cim = 0;
+            if (!busy && col < vw && row < vh) { /* row < vh <= 16 also bounds pix */
+                sx = s_x[col], sy = s_y[row];
+                cre = julia ? jre : sx, cim = julia ? jim : sy; /* calc/src/lib.rs:209-210 */
+                X = sx + sx, Y = sy + sy, A = X * X, B = Y * Y, c2re = cre + cre, c2im = cim + cim;
                 px = pcol0 + col;
                 py = s_orow[row];
-                done = 0;
-                busy = true;
+                cnt = 0.0f;
+                /* the scaled form must be provably exact for this pixel, and it must start under T */
+                if (lane_is_scalable<T>(sx, sy, cre, cim) && A + B <= t4 && cap >= (uint32_t)M)
+                    busy = true;
+                else
+                    direct = true;
             }
             next += (uint32_t)__builtin_popcountll(free_mask);
-            if (next >= kQPatchPx || (next >> 6) >= vh) have_patch = false;
+            if ((next >> 6) >= vh) have_patch = 0;
+            push(direct, sx, sy, cre, cim, 0u);
             busy_mask = __ballot(busy);
         }
+        FR_PHASE_END(ph_refill);
         if (busy_mask == 0ull) {
-            if (exhausted && !held) break;
-            continue; /* drained: the held patch can be opened now */
+            if (!have_patch && exhausted) break;
+            continue;
         }
-
-        /* ---- one episode */
-        if (upper >= cap) upper = wave_max_u32(busy ? done : 0u); /* every busy lane has done < cap */
-        const uint32_t n = cap - upper;
+        /* ---- 3. one run of the main loop */
+        FR_PHASE_BEGIN();
+        if (upper + (uint32_t)M > cap) upper = wave_max_u32(busy ? (uint32_t)cnt : 0u); /* every busy lane: cnt + M <= cap */
+        const uint32_t nblocks = (cap - upper) / (uint32_t)M;
         const uint32_t nbusy = (uint32_t)__builtin_popcountll(busy_mask);
-        EpisodeCtl ctl{0u, 0u};
-        if (!(exhausted && !have_patch && !held) && !held) {
-            /* more pixels are waiting: stop once `want` lanes have finished (and minrun iterations were done) */
-            ctl = EpisodeCtl{nbusy > queue_want ? nbusy - queue_want : 0u, queue_minrun};
+        uint32_t thr = 0, minblocks = 0;
+        if (have_patch || !exhausted) { /* more pixels wait: stop once `queue_want` lanes are free */
+            thr = nbusy > queue_want ? nbusy - queue_want : 0u;
+            minblocks = queue_minblocks;
         }
-        uint32_t it = 0, completed = 0;
-        if (busy) {
-            if constexpr (M != 0) {
-                if (scaled)
-                    it = orbit_scaled_run<T, M, false>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed);
-                else
-                    it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
-            } else {
-                it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
-            }
-        }
-        /* wave-uniform, but assigned under `if (busy)`: take it from a lane that ran the episode */
-        completed = __builtin_amdgcn_readlane(completed, (int)__builtin_ctzll(busy_mask));
-        upper += completed;
-
-        /* ---- retire: finished lanes push their result and become free */
-        bool fin = false;
-        uint32_t iters = 0;
-        if (busy) {
-            const bool escaped = it < completed;
-            iters = escaped ? done + it : cap;
-            done += completed;
-            fin = escaped || done >= cap;
-        }
-        const unsigned long long fin_mask = __ballot(fin);
-        if (fin_mask != 0ull) {
-            if (fin) {
-                const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(fin_mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)fin_mask, 0u));
-                q_re[slot] = scaled ? a0 * (T)0.5 : a0; /* exact */
-                q_im[slot] = scaled ? a1 * (T)0.5 : a1;
-                q_it[slot] = iters;
-                q_px[slot] = px;
-                q_py[slot] = py;
-                busy = false;
-            }
-            qcount += (uint32_t)__builtin_popcountll(fin_mask);
-            if (qcount >= 64u) {
-                /* colour map + store of 64 waiting results: a full wave */
-                __syncthreads();
-                const uint32_t e = qcount - 64u + lane;
-                const double zre = (double)q_re[e], zim = (double)q_im[e];
-                uint8_t rgb[3];
-                FR_COLD_PARAMS(kp);
-                const ColourConsts cc = make_colour_consts(*kp);
-                colour_of(cc, zre * zre + zim * zim, q_it[e], tab, s_pal, rgb); /* pos.squared_distance(), :214 */
-                store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[e], q_px[e], rgb);
-                qcount -= 64u;
-                __syncthreads();
-            }
-        }
+        unsigned long long running = 0ull;
+        uint32_t blocks = 0;
+        if (busy) blocks = queue_block_run<T, M>(nblocks, X, Y, A, B, c2re, c2im, skip_t, cnt, thr, minblocks, running);
+        const int first = (int)__builtin_ctzll(busy_mask);
+        blocks = __builtin_amdgcn_readlane(blocks, first); /* wave-uniform, but assigned under `if (busy)` */
+        running = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(running >> 32), first) << 32) |
+                  (uint32_t)__builtin_amdgcn_readlane((uint32_t)running, first);
+        upper += blocks * (uint32_t)M;
+        tr_episodes++;
+        tr_iters += blocks * (uint32_t)M;
+        FR_PHASE_END(ph_loop);
+        /* ---- 4. retire: lanes that froze past T, and lanes that cannot fit another block under the cap */
+        FR_PHASE_BEGIN();
+        const bool still = busy && ((running >> lane) & 1ull) != 0ull;
+        const bool capped = still && (uint32_t)cnt + (uint32_t)M > cap;
+        const bool leave = busy && (!still || capped);
+        if (leave) busy = false;
+        push(leave, X * (T)0.5, Y * (T)0.5, c2re * (T)0.5, c2im * (T)0.5, (uint32_t)cnt); /* exact halvings */
+        FR_PHASE_END(ph_retire);
     }
     /* ---- the last, partial batch */
-    __syncthreads();
-    if (lane < qcount) {
-        const double zre = (double)q_re[lane], zim = (double)q_im[lane];
-        uint8_t rgb[3];
-        FR_COLD_PARAMS(kp);
-        const ColourConsts cc = make_colour_consts(*kp);
-        colour_of(cc, zre * zre + zim * zim, q_it[lane], tab, s_pal, rgb);
-        store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[lane], q_px[lane], rgb);
+    if (qcount) finish_and_colour(0u, qcount);
+    if (out.trace && lane == 0) {
+        unsigned long long *t = out.trace + (size_t)blockIdx.x * 16;
+        t[0] = t_start, t[1] = __builtin_amdgcn_s_memrealtime(), t[2] = tr_patches, t[3] = tr_episodes, t[4] = tr_colour,
+        t[5] = tr_iters, t[6] = (ph_open & 0xFFFFFFFFull) | (ph_refill << 32), t[7] = (ph_loop & 0xFFFFFFFFull) | (ph_retire << 32);
+        t[8] = ph_finish;
     }
+#undef FR_COLD_PARAMS
+#undef FR_PHASE_BEGIN
+#undef FR_PHASE_END
 }
 
 template <typename T, int M>
@@ -1309,10 +1390,11 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
     const uint64_t npx = ((uint64_t)p.ncols + kQPatchW - 1) / kQPatchW;
     const uint64_t npy = ((uint64_t)p.nrows + kQPatchH - 1) / kQPatchH;
     if (npx * npy == 0) return hipSuccess;
-    if (npx * npy > 0xFFF00000ull) return hipErrorInvalidConfiguration; /* the counter overshoots by <= 2 batches per wave */
+    if (npx * npy > 0xFFF00000ull) return hipErrorInvalidConfiguration; /* the counter overshoots by one per wave */
     const size_t dyn = p.palette ? sizeof(uint32_t) * p.palette_entries : 0;
-    /* persistent grid: as many one-wave workgroups as the device holds at once (asking for a few more
-     * than that is harmless: a late workgroup finds the counter exhausted and leaves) */
+    /* persistent grid: as many one-wave workgroups as the device holds at once (the occupancy query ignores
+     * the SGPR budget and can answer a few too many per CU; harmless: a late workgroup finds the counter
+     * exhausted and leaves) */
     static thread_local int cached_device = -1, cached_cus = 0;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1337,8 +1419,7 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
 template <typename T>
 hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
     if (p.loop_mode == 4) return launch_queue_form<T, 4>(p, out, stream);
-    if (p.loop_mode == 2) return launch_queue_form<T, 2>(p, out, stream);
-    return launch_queue_form<T, 0>(p, out, stream);
+    return launch_queue_form<T, 2>(p, out, stream);
 }
 
 template <typename T, int kStripTiles>
@@ -1414,7 +1495,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
-            if (p.algo == 2 && mode == FR_OUT_RGB && p.work_counter && !p.cycle_shortcut) {
+            if (p.algo == 2 && mode == FR_OUT_RGB && p.work_counter && fr_wants_work_queue(p, 0)) {
                 name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x16-px patches");
                 return launch_queue<T>(p, out, stream);
             }
@@ -1440,7 +1521,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
     case 10: /* the work-queue kernel (RGB output of an escape-time algorithm; otherwise as 9) */
-        if ((p.algo == 0 || p.algo == 2) && mode == FR_OUT_RGB && p.work_counter && !p.cycle_shortcut) {
+        if (mode == FR_OUT_RGB && p.work_counter && fr_wants_work_queue(p, 10)) {
             name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x16-px patches");
             return launch_queue<T>(p, out, stream);
         }
@@ -1557,6 +1638,8 @@ __global__ __launch_bounds__(256) void nu_scan_kernel(uint32_t lo, uint32_t hi, 
 
 bool fr_wants_work_queue(const fr_kparams &p, int tile) {
     if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
+    /* its main loop is the scaled form in blocks of loop_mode iterations, counted in an f32 */
+    if (p.loop_mode == 0 || p.iterations >= (1u << 24)) return false;
     if (tile == 10) return true;
     if (tile != 0 || p.algo != 2) return false;
     return (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8) >= 262144;

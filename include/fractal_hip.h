@@ -339,6 +339,9 @@ int fr_set_loop_mode(int mode);
  * so tests can compare the device's roundings with the host's; which = 4: the colour filter's
  * bracket centre against the f64 nu over EVERY f32 bit pattern in [in[0], in[1]], out[0] = worst error. */
 int fr_debug_math(int which, const double *in, double *out, size_t n);
+/* Tuning aid: a device buffer of 16 uint64 per persistent wave (8192 waves is enough) to which the work-queue
+ * kernel's waves write their start / end times (100 MHz ticks) and work counts; NULL turns it off. */
+int fr_debug_set_queue_trace(void *d_trace);
 
 #ifdef __cplusplus
 }
