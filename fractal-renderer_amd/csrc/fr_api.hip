@@ -135,7 +135,15 @@ int Ctx::create(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    /* D2H and peer copies of registered memory run as shader (blit) kernels on this runtime: give their
+     * stream the highest priority so that they get the few CUs they need while render kernels fill the chip
+     * (the PCIe link, not the copy kernel, is the limit) */
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        prio_greatest = 0;
+    }
+    HIP_TRY(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_greatest));
     hip_device = device;
     return FR_OK;
 }

@@ -1073,14 +1073,14 @@ hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipS
  *                  then the colour map and the store.  Pixels that may not use the scaled form at all
  *                  (the im == 0 row, the re == 0 column) and lanes within M iterations of the cap take the
  *                  same road with their whole remaining orbit.
- *   persistent     waves draw 64 x 16-pixel patches from a device-wide counter (one ahead, so the atomic's
+ *   persistent     waves draw 64 x 32-pixel patches from a device-wide counter (one ahead, so the atomic's
  *                  latency is never waited for): a lane's pixel outlives its patch and the only tail is
  *                  the one at the end of the image.  A patch's column / row coordinates
  *                  (calc/src/lib.rs:181-197: two IEEE divisions per column and per row, not per pixel) are
  *                  staged in LDS when it is opened; a refill is two LDS reads and two multiplies.
  * Results are independent of the schedule: a pixel's orbit never depends on its lane, its wave, the order
  * of patches or where the main loop hands it over. */
-constexpr uint32_t kQPatchW = 64, kQPatchH = 16;
+constexpr uint32_t kQPatchW = 64, kQPatchH = 32;
 constexpr uint32_t kQStack = 128;
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -1154,6 +1154,57 @@ __device__ __forceinline__ uint32_t queue_block_run(uint32_t nblocks, T &X, T &Y
     return si;
 }
 
+/* The finishing pass's loop: recursive()'s own iteration (unscaled, 8 VALU) with the escape test after every
+ * one — v_cmpx freezes a lane at `next`, exactly what recursive() returns — and a per-lane f32 count of the
+ * iterations run (frozen with the lane), so no escape-index handler and no scalar work beyond the loop
+ * control.  In: EXEC = the lanes to finish; out: `running` = the lanes that did not escape within n. */
+#define FR_FIN_ASM(SFX)                                \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    "s_mov_b32 %[si], 0\n"                             \
+    "s_cbranch_execz .Lfdone_%=\n"                     \
+    ".Lfloop_%=:\n"                                    \
+    "v_add_" SFX " %[t], %[r2], -%[i2]\n"              \
+    "v_add_" SFX " %[x], %[re], %[re]\n"               \
+    "v_add_" SFX " %[re], %[t], %[cre]\n"              \
+    "v_mul_" SFX " %[x], %[x], %[im]\n"                \
+    "v_add_" SFX " %[im], %[x], %[cim]\n"              \
+    "v_mul_" SFX " %[r2], %[re], %[re]\n"              \
+    "v_mul_" SFX " %[i2], %[im], %[im]\n"              \
+    "v_add_" SFX " %[t], %[r2], %[i2]\n"               \
+    "v_add_f32 %[fc], 1.0, %[fc]\n"                    \
+    "v_cmpx_nlt_" SFX " %[lim2], %[t]\n"               \
+    "s_cbranch_execz .Lfdone_%=\n"                     \
+    "s_add_u32 %[si], %[si], 1\n"                      \
+    "s_cmp_lt_u32 %[si], %[n]\n"                       \
+    "s_cbranch_scc1 .Lfloop_%=\n"                      \
+    ".Lfdone_%=:\n"                                    \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"
+
+template <typename T>
+__device__ __forceinline__ unsigned long long finish_run(uint32_t iterations, T &re, T &im, T &r2, T &i2, T cre, T cim, T squared,
+                                                         float &fc) {
+    T t, x;
+    unsigned long long sorig, srun;
+    uint32_t si;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
+#define FR_FIN_OPERANDS                                                                                       \
+    : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [fc] "+v"(fc), [t] "=&v"(t), [x] "=&v"(x),  \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [si] "=&s"(si)                                                \
+    : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n)                                            \
+    : "vcc", "scc"
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t sq_bits = fr_bits_of(squared);
+        const uint64_t lim2 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sq_bits) |
+                              ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sq_bits >> 32)) << 32);
+        asm volatile(FR_FIN_ASM("f64") FR_FIN_OPERANDS);
+    } else {
+        const uint32_t lim2 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, squared));
+        asm volatile(FR_FIN_ASM("f32") FR_FIN_OPERANDS);
+    }
+    return srun;
+}
+
 template <typename T, int M>
 __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, const fr_kout out, uint32_t npatch_x,
                                                           uint32_t npatches) {
@@ -1203,6 +1254,7 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     bool busy = false;
     /* wave-uniform state */
     uint32_t have_patch = 0, exhausted = 0, next = 0, vw = 0, vh = 0, pcol0 = 0;
+    uint32_t patch_ok = 0; /* every pixel of the open patch may use the scaled form (all but a sliver of patches) */
     uint32_t qcount = 0, upper = 0; /* results waiting; upper bound of the running lanes' iteration counts */
     uint32_t pref = 0;              /* lane 0: the id of the next patch (requested one patch ahead) */
     if (lane == 0) pref = atomicAdd(counter, 1u);
@@ -1222,22 +1274,28 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
         const bool escaped0 = mine && done > 0u && r2 + i2 > squared; /* NaN: false, as in the reference */
         bool live = mine && !escaped0 && done < cap;
         uint32_t iters = escaped0 ? done - 1u : cap;
-        /* exact per-iteration checks for whoever is not finished: the unscaled loop, as many rounds as the
-         * lanes' different distances to the cap need (one, unless a lane is about to hit the cap) */
-        while (__ballot(live) != 0ull) {
-            const uint32_t n = wave_min_u32(live ? cap - done : 0xFFFFFFFFu);
-            uint32_t it = 0, completed = 0;
-            if (live) it = orbit_run<T>(n, re, im, cre, cim, squared, r2, i2, EpisodeCtl{0u, 0u}, completed);
+        /* exact per-iteration checks for whoever is not finished.  A round runs up to 64 iterations — a pixel
+         * past T is 4-5 iterations from limit^2 — unless a lane is that close to the cap: then the round's length
+         * is the smallest remaining count (a wave reduction: rare) */
+        float fc = (float)done;
+        for (;;) {
+            const unsigned long long live_mask = __ballot(live);
+            if (live_mask == 0ull) break;
+            uint32_t n = 64u;
+            if (__ballot(live && cap - done < 64u) != 0ull) n = wave_min_u32(live ? cap - done : 0xFFFFFFFFu);
+            unsigned long long running = 0ull;
+            if (live) running = finish_run<T>(n, re, im, r2, i2, cre, cim, squared, fc);
+            const int first = (int)__builtin_ctzll(live_mask);
+            running = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(running >> 32), first) << 32) |
+                      (uint32_t)__builtin_amdgcn_readlane((uint32_t)running, first);
             if (live) {
-                if (it < completed) { /* escaped at index it of this run */
-                    iters = done + it;
+                done = (uint32_t)fc;
+                if (((running >> lane) & 1ull) == 0ull) { /* escaped in the iteration that made the count `done` */
+                    iters = done - 1u;
                     live = false;
-                } else {
-                    done += completed;
-                    if (done >= cap) {
-                        iters = cap;
-                        live = false;
-                    }
+                } else if (done >= cap) {
+                    iters = cap;
+                    live = false;
                 }
             }
         }
@@ -1295,6 +1353,11 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
                 pcol0 = pxi * kQPatchW;
                 vw = ncols - pcol0 < kQPatchW ? ncols - pcol0 : kQPatchW;
                 vh = nrows - prow0 < kQPatchH ? nrows - prow0 : kQPatchH;
+                const double pjre = P.julia_re, pjim = P.julia_im;
+                patch_ok = coords_admissible<T>(julia, pjre, pjim, cx, col < ncols) &&
+                                   coords_admissible<T>(julia, pjre, pjim, cy, lane < kQPatchH && rr < nrows)
+                               ? 1u
+                               : 0u;
                 __syncthreads(); /* earlier reads of s_x / s_y are done */
                 s_x[lane] = (T)cx;
                 if (lane < kQPatchH) {
@@ -1319,7 +1382,7 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
             const uint32_t col = pix & (kQPatchW - 1), row = pix >> 6;
             bool direct = false; /* this pixel cannot enter the main loop: straight to the finishing pass */
             T sx = 0, sy = 0, cre = 0, cim = 0;
-            if (!busy && col < vw && row < vh) { /* row < vh <= 16 also bounds pix */
+            if (!busy && col < vw && row < vh) { /* row < vh <= kQPatchH also bounds pix */
                 sx = s_x[col], sy = s_y[row];
                 cre = julia ? jre : sx, cim = julia ? jim : sy; /* calc/src/lib.rs:209-210 */
                 X = sx + sx, Y = sy + sy, A = X * X, B = Y * Y, c2re = cre + cre, c2im = cim + cim;
@@ -1327,7 +1390,7 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
                 py = s_orow[row];
                 cnt = 0.0f;
                 /* the scaled form must be provably exact for this pixel, and it must start under T */
-                if (lane_is_scalable<T>(sx, sy, cre, cim) && A + B <= t4 && cap >= (uint32_t)M)
+                if ((patch_ok || lane_is_scalable<T>(sx, sy, cre, cim)) && A + B <= t4 && cap >= (uint32_t)M)
                     busy = true;
                 else
                     direct = true;
@@ -1496,7 +1559,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
             if (p.algo == 2 && mode == FR_OUT_RGB && p.work_counter && fr_wants_work_queue(p, 0)) {
-                name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x16-px patches");
+                name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x32-px patches");
                 return launch_queue<T>(p, out, stream);
             }
             if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) {
@@ -1522,7 +1585,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         return launch_strips<T, 7>(p, mode, out, stream);
     case 10: /* the work-queue kernel (RGB output of an escape-time algorithm; otherwise as 9) */
         if (mode == FR_OUT_RGB && p.work_counter && fr_wants_work_queue(p, 10)) {
-            name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x16-px patches");
+            name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x32-px patches");
             return launch_queue<T>(p, out, stream);
         }
         [[fallthrough]];
