@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -122,10 +123,15 @@ struct LifeExclusive {
  * several threads), then the chunk is pinned with hipHostRegister.  `portable` = for every device. */
 class ChunkPinner {
   public:
-    ChunkPinner(uint8_t *out, size_t need, bool portable);
+    /* byte_order (optional): image byte offsets in the order the caller will need them, so that the first
+     * touch runs ahead in that order */
+    ChunkPinner(uint8_t *out, size_t need, bool portable, const std::vector<size_t> *byte_order = nullptr);
     ~ChunkPinner();
-    /* pins the next chunk: bytes [a, b) of the buffer; pinned = false: could not be pinned (plain copy).
-     * Returns false when the walk is over. */
+    size_t chunks() const { return bounds_.size() - 1; }
+    size_t bound(size_t k) const { return bounds_[k]; } /* chunk k = bytes [bound(k), bound(k + 1)) */
+    size_t chunk_of(size_t byte) const;
+    bool pin(size_t k); /* waits for the chunk's first touch, pins it once; false: it cannot be pinned (plain copy) */
+    /* the chunks in address order: pins the next one, bytes [a, b); returns false when the walk is over */
     bool next(size_t &a, size_t &b, bool &pinned);
     void release(); /* unpin everything (the caller drained its streams first) */
     /* where the chunk starting at byte `a` ends: a pure function of (out, need, a), so that other threads
@@ -137,7 +143,9 @@ class ChunkPinner {
     uint8_t *out_;
     size_t need_, pos_ = 0;
     unsigned flags_;
-    std::atomic<size_t> touched_{0};
+    std::vector<size_t> bounds_;
+    std::unique_ptr<std::atomic<int>[]> state_; /* 0: pages may not exist yet, 1: touched */
+    std::vector<char> pinned_;                  /* 0: not tried, 1: pinned, 2: cannot be pinned */
     std::thread toucher_;
     std::vector<uint8_t *> regs_;
 };

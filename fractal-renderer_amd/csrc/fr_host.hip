@@ -122,43 +122,80 @@ size_t ChunkPinner::chunk_end(const uint8_t *out, size_t need, size_t a) {
     return b > a ? b : need;
 }
 
-ChunkPinner::ChunkPinner(uint8_t *out, size_t need, bool portable)
+ChunkPinner::ChunkPinner(uint8_t *out, size_t need, bool portable, const std::vector<size_t> *byte_order)
     : out_(out), need_(need), flags_(portable ? hipHostRegisterPortable : hipHostRegisterDefault) {
+    for (size_t a = 0; a < need;) {
+        const size_t b = chunk_end(out, need, a);
+        bounds_.push_back(a);
+        a = b;
+    }
+    bounds_.push_back(need);
+    const size_t n = chunks();
+    state_.reset(new std::atomic<int>[n]);
     const bool fresh = !looks_resident(out, need < 4 * kChunk ? need : 4 * kChunk);
-    touched_.store(fresh ? 0 : need);
+    for (size_t k = 0; k < n; k++) state_[k].store(fresh ? 0 : 1);
+    pinned_.assign(n, 0);
     if (fresh) {
-        /* the toucher runs ahead of the pinning loop; bytes [0, touched_) are faulted in */
-        toucher_ = std::thread([this] {
-            for (size_t a = 0; a < need_; a += kChunk) {
-                const size_t b = a + kChunk < need_ ? a + kChunk : need_;
-                prefault(out_ + a, b - a);
-                touched_.store(b, std::memory_order_release);
+        /* the toucher runs ahead of the pinning: chunks in the order they will be needed */
+        std::vector<size_t> order;
+        std::vector<char> seen(n, 0);
+        if (byte_order)
+            for (size_t byte : *byte_order) {
+                const size_t k = chunk_of(byte < need ? byte : need - 1);
+                if (!seen[k]) seen[k] = 1, order.push_back(k);
+            }
+        for (size_t k = 0; k < n; k++)
+            if (!seen[k]) order.push_back(k);
+        toucher_ = std::thread([this, order] {
+            for (size_t k : order) {
+                prefault(out_ + bounds_[k], bounds_[k + 1] - bounds_[k]);
+                state_[k].store(1, std::memory_order_release);
             }
         });
     }
 }
 
-bool ChunkPinner::next(size_t &a, size_t &b, bool &pinned) {
-    if (pos_ >= need_) return false;
+size_t ChunkPinner::chunk_of(size_t byte) const {
+    size_t lo = 0, hi = chunks(); /* bounds_[lo] <= byte < bounds_[hi] */
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (bounds_[mid] <= byte) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+/* waits until chunk k's pages exist, then pins it (once); false = it cannot be pinned: plain copies */
+bool ChunkPinner::pin(size_t k) {
+    if (pinned_[k]) return pinned_[k] == 1;
     const uintptr_t base = reinterpret_cast<uintptr_t>(out_);
-    a = pos_;
-    b = chunk_end(out_, need_, a);
+    const size_t a = bounds_[k], b = bounds_[k + 1];
     const double t0 = now_ms();
-    while (touched_.load(std::memory_order_acquire) < b) std::this_thread::yield();
+    while (state_[k].load(std::memory_order_acquire) == 0) std::this_thread::yield();
     const double t1 = now_ms();
+    /* interior boundaries are page boundaries of the host address; the two outer ones are rounded outwards */
     uint8_t *ra = reinterpret_cast<uint8_t *>((base + a) & ~(kPage - 1));
     uint8_t *rb = b < need_ ? out_ + b : reinterpret_cast<uint8_t *>((base + b + kPage - 1) & ~(kPage - 1));
     const hipError_t re = hipHostRegister(ra, (size_t)(rb - ra), flags_);
-    pinned = re == hipSuccess;
-    if (pinned) {
+    bool ok = re == hipSuccess;
+    if (ok) {
         regs_.push_back(ra);
     } else {
         (void)hipGetLastError();
-        pinned = re == hipErrorHostMemoryAlreadyRegistered; /* the caller pinned it: even better */
+        ok = re == hipErrorHostMemoryAlreadyRegistered; /* the caller pinned it: even better */
     }
+    pinned_[k] = ok ? 1 : 2;
     t_touch += t1 - t0;
     t_reg += now_ms() - t1;
-    pos_ = b;
+    return ok;
+}
+
+bool ChunkPinner::next(size_t &a, size_t &b, bool &pinned) {
+    if (pos_ >= chunks()) return false;
+    a = bounds_[pos_];
+    b = bounds_[pos_ + 1];
+    pinned = pin(pos_);
+    pos_++;
     return true;
 }
 
@@ -203,62 +240,101 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     }
 
     /* 1. every band's kernel, enqueued up front: the GPU renders while the host prepares the buffer.  Bands
-     *    follow the copy chunks (a chunk can leave as soon as the band that completes it is done) and
-     *    alternate between two streams, so that the tail of one band's kernel — its few longest strips —
-     *    overlaps the start of the next instead of idling the GPU (one stream: +20 %). */
-    std::vector<size_t> band_end; /* byte offset where band k ends */
-    hipError_t err = hipSuccess;
-    const char *what = "";
+     *    are ~64 MiB of whole 8-row tiles (smaller over the last stretch) and alternate between two streams,
+     *    so that the tail of one band's kernel — its few longest strips — overlaps the start of the next.
+     *    They are issued in BIT-REVERSED order: the set's interior makes neighbouring bands similarly cheap
+     *    or similarly expensive (default view: 0.3 ms at the top, 4 ms in the middle), and in image order the
+     *    copy engine first starves behind the expensive middle, then finds a third of the image finished at
+     *    once; a bit-reversed prefix samples the image evenly, so finished bytes arrive at a steady rate. */
+    struct Band {
+        uint32_t ya, yb;
+        size_t a, b; /* byte range of the image */
+    };
+    std::vector<Band> bands;
     {
         uint32_t ya = y0;
         size_t a = 0;
-        while (ya < y1 && rc == FR_OK) {
-            const size_t b = ChunkPinner::chunk_end(out, need, a);
-            uint64_t rows = (b - row_bytes * (size_t)(ya - y0) + row_bytes - 1) / row_bytes; /* rows covering the chunk */
-            rows = (rows + 7) / 8 * 8;                                                       /* whole 8-row tiles */
+        while (ya < y1) {
+            const size_t target = ChunkPinner::chunk_end(out, need, a);
+            uint64_t rows = (target - a + row_bytes - 1) / row_bytes;
+            rows = (rows + 7) / 8 * 8; /* whole 8-row tiles */
             const uint32_t yb = (uint32_t)((uint64_t)ya + rows < y1 ? ya + rows : y1);
-            hipStream_t st = (band_end.size() & 1) ? ctx.stream2 : ctx.stream;
-            rc = render_on(st, ya, yb, scratch + row_bytes * (size_t)(ya - y0));
-            if (rc != FR_OK) break;
-            hipEvent_t e;
-            rc = ctx.event(band_end.size(), &e);
-            if (rc != FR_OK) break;
-            if ((err = hipEventRecord(e, st)) != hipSuccess) {
-                what = "hipEventRecord";
-                break;
-            }
-            band_end.push_back(row_bytes * (size_t)(yb - y0));
+            const size_t b = row_bytes * (size_t)(yb - y0);
+            bands.push_back(Band{ya, yb, a, b});
             ya = yb;
             a = b;
         }
     }
+    std::vector<size_t> order;
+    {
+        size_t pow2 = 1;
+        int bits = 0;
+        while (pow2 < bands.size()) pow2 <<= 1, bits++;
+        for (size_t i = 0; i < pow2; i++) {
+            size_t r = 0;
+            for (int k = 0; k < bits; k++) r |= ((i >> k) & 1u) << (bits - 1 - k);
+            if (r < bands.size()) order.push_back(r);
+        }
+    }
+    hipError_t err = hipSuccess;
+    const char *what = "";
+    std::vector<hipEvent_t> tk, tc; /* FR_TRACE only: when each band's kernel / copy finished */
+    hipEvent_t t_zero = nullptr;
+    if (trace && hipEventCreate(&t_zero) == hipSuccess) (void)hipEventRecord(t_zero, ctx.stream);
+    for (size_t i = 0; i < order.size() && rc == FR_OK && err == hipSuccess; i++) {
+        const Band &bd = bands[order[i]];
+        hipStream_t st = (i & 1) ? ctx.stream2 : ctx.stream;
+        rc = render_on(st, bd.ya, bd.yb, scratch + bd.a);
+        if (rc != FR_OK) break;
+        hipEvent_t e;
+        rc = ctx.event(i, &e);
+        if (rc != FR_OK) break;
+        if ((err = hipEventRecord(e, st)) != hipSuccess) what = "hipEventRecord";
+        if (t_zero) {
+            hipEvent_t te;
+            if (hipEventCreate(&te) == hipSuccess) {
+                (void)hipEventRecord(te, st);
+                tk.push_back(te);
+            }
+        }
+    }
     const double t_launched = now_ms();
 
-    /* 2. the caller's buffer chunk by chunk: pin, then DMA behind the band that completes the chunk */
-    ChunkPinner pinner(out, need, false);
-    if (rc == FR_OK && err == hipSuccess) {
-        size_t a, b, band = 0;
-        bool pinned;
-        while (err == hipSuccess && pinner.next(a, b, pinned)) {
-            while (band + 1 < band_end.size() && band_end[band] < b) band++;
-            /* bands alternate between two streams: the chunk needs every band up to `band`, i.e. the last
-             * one on each stream */
-            hipEvent_t e;
-            rc = ctx.event(band, &e); /* recorded above */
-            if (rc != FR_OK) break;
-            hipEvent_t e_prev = nullptr;
-            if (band > 0) rc = ctx.event(band - 1, &e_prev);
-            if (rc != FR_OK) break;
-            if (pinned) {
-                if ((err = hipStreamWaitEvent(ctx.copy_stream, e, 0)) != hipSuccess) what = "hipStreamWaitEvent";
-                else if (e_prev && (err = hipStreamWaitEvent(ctx.copy_stream, e_prev, 0)) != hipSuccess) what = "hipStreamWaitEvent";
-                else if ((err = hipMemcpyAsync(out + a, scratch + a, b - a, hipMemcpyDeviceToHost, ctx.copy_stream)) != hipSuccess)
+    /* 2. the caller's buffer, band by band in the same order: first touch (a background thread, ahead of us)
+     *    and pin of the 64 MiB chunks the band lies in, then its DMA behind its kernel — split where two pins
+     *    meet (one DMA must not span two registrations) */
+    std::vector<size_t> byte_order;
+    for (size_t k : order) byte_order.push_back(bands[k].a);
+    ChunkPinner pinner(out, need, false, &byte_order);
+    for (size_t i = 0; i < order.size() && rc == FR_OK && err == hipSuccess; i++) {
+        const Band &bd = bands[order[i]];
+        hipEvent_t e;
+        rc = ctx.event(i, &e); /* recorded above */
+        if (rc != FR_OK) break;
+        bool waited = false;
+        for (size_t pos = bd.a; pos < bd.b && err == hipSuccess;) {
+            const size_t k = pinner.chunk_of(pos);
+            const size_t end = pinner.bound(k + 1) < bd.b ? pinner.bound(k + 1) : bd.b;
+            if (pinner.pin(k)) {
+                if (!waited) {
+                    if ((err = hipStreamWaitEvent(ctx.copy_stream, e, 0)) != hipSuccess) what = "hipStreamWaitEvent";
+                    waited = true;
+                }
+                if (err == hipSuccess &&
+                    (err = hipMemcpyAsync(out + pos, scratch + pos, end - pos, hipMemcpyDeviceToHost, ctx.copy_stream)) != hipSuccess)
                     what = "hipMemcpyAsync";
             } else {
-                /* memory that cannot be pinned: a plain (staged) copy once its bands are done */
+                /* memory that cannot be pinned: a plain (staged) copy once the band is done */
                 if ((err = hipEventSynchronize(e)) != hipSuccess) what = "hipEventSynchronize";
-                else if (e_prev && (err = hipEventSynchronize(e_prev)) != hipSuccess) what = "hipEventSynchronize";
-                else if ((err = hipMemcpy(out + a, scratch + a, b - a, hipMemcpyDeviceToHost)) != hipSuccess) what = "hipMemcpy";
+                else if ((err = hipMemcpy(out + pos, scratch + pos, end - pos, hipMemcpyDeviceToHost)) != hipSuccess) what = "hipMemcpy";
+            }
+            pos = end;
+        }
+        if (t_zero) {
+            hipEvent_t te;
+            if (hipEventCreate(&te) == hipSuccess) {
+                (void)hipEventRecord(te, ctx.copy_stream);
+                tc.push_back(te);
             }
         }
     }
@@ -276,6 +352,24 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
                 "enqueued at %.2f, drained at %.2f, unpinned at %.2f\n",
                 need, t_launched - t_start, pinner.t_touch, pinner.t_reg, t_enqueued - t_start, t_synced - t_start,
                 now_ms() - t_start);
+    if (t_zero) {
+        fprintf(stderr, "[fr_host]   band kernels done at (ms):");
+        for (hipEvent_t e : tk) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, t_zero, e);
+            fprintf(stderr, " %.1f", ms);
+            (void)hipEventDestroy(e);
+        }
+        fprintf(stderr, "\n[fr_host]   chunk copies done at (ms):");
+        for (hipEvent_t e : tc) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, t_zero, e);
+            fprintf(stderr, " %.1f", ms);
+            (void)hipEventDestroy(e);
+        }
+        fprintf(stderr, "\n");
+        (void)hipEventDestroy(t_zero);
+    }
     if (rc != FR_OK) return rc;
     if (err != hipSuccess) return fail_hip(err, what);
     if (e1 != hipSuccess) return fail_hip(e1, "hipStreamSynchronize(stream)");

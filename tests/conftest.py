@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # before anything loads libfractal_hip.so: the library then binds to the HIP runtime torch carries
+    import torch  # noqa: F401  (in a process that uses both, torch must come first)
+except ImportError:
+    pass
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 for p in (HERE, ROOT):

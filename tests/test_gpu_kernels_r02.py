@@ -154,8 +154,9 @@ def test_colour_filter_full_size_c2_identical(fr, lib):
 
 QUEUE_CASES = [
     dict(width=1237, height=1001, iterations=300, algo=O.JULIA, julia_set=(-0.8, 0.156)),       # ragged both ways
-    dict(width=64, height=16, iterations=100, algo=O.JULIA, julia_set=(-0.8, 0.156)),           # exactly one patch
-    dict(width=65, height=17, iterations=100, algo=O.JULIA, julia_set=(0.285, 0.01)),           # one px over in both
+    dict(width=64, height=32, iterations=100, algo=O.JULIA, julia_set=(-0.8, 0.156)),           # exactly one patch
+    dict(width=65, height=33, iterations=100, algo=O.JULIA, julia_set=(0.285, 0.01)),           # one px over in both
+    dict(width=64, height=16, iterations=100, algo=O.JULIA, julia_set=(-0.8, 0.156)),           # half a patch
     dict(width=3, height=2, iterations=50),                                                     # smaller than a patch row
     dict(width=700, height=520, iterations=400),                                                # Mandelbrot: lanes hit the cap
     dict(width=700, height=520, iterations=400, smooth=0),                                      # palette in dynamic LDS
@@ -225,9 +226,9 @@ def test_work_queue_kernel_row_bands_rgba_and_in_place_blocks(fr, lib):
 
 @pytest.mark.parametrize("prec_name", ["f32", "f64"])
 def test_full_size_c4_work_queue_kernel(fr, lib, prec_name):
-    """BASELINE C4 (Julia, 16384^2, 4096 iterations) through the default dispatch = the work-queue kernel:
-    every 16th pixel against the oracle (libm log2), the 180-degree symmetry of the Julia image, and byte
-    identity with the patch-refill kernel (tile 9) and with the colour filter off."""
+    """BASELINE C4 (Julia, 16384^2, 4096 iterations) through the work-queue kernel (tile 10): every 16th pixel
+    against the oracle (libm log2), the 180-degree symmetry of the Julia image, and byte identity with the
+    default dispatch (the patch-refill kernel) and with the colour filter off."""
     import torch
     from fractal_renderer_amd import _native
 
@@ -248,18 +249,18 @@ def test_full_size_c4_work_queue_kernel(fr, lib, prec_name):
         _native.check(lib.fr_set_profiling(0))
         return d, name.value
 
-    img, name = render()
+    img, name = render(tile=10)
     assert name.startswith(b"escape_queue_kernel"), name
     torch.cuda.synchronize()
     total, npx, want = O.sample_image(ocfg, 16, 16, O.F32 if prec else O.F64)
     view = img.view(16384, 16384, 3)
     assert np.array_equal(view[::16, ::16].cpu().numpy(), want)
     assert torch.equal(view[1:, 1:], torch.flip(view[1:, 1:], dims=(0, 1)))
-    other, name9 = render(tile=9)
+    other, name9 = render()
     assert name9.startswith(b"escape_refill_kernel"), name9
     assert torch.equal(img, other)
     del other
-    exact, _ = render(colour_filter=0)
+    exact, _ = render(tile=10, colour_filter=0)
     assert torch.equal(img, exact)
 
 
