@@ -15,6 +15,7 @@ from fractal_renderer_amd import _native  # noqa: E402
 prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else 0
 lib = _native.load()
 fr.init(0)
+_native.check(lib.fr_set_tile(10))  # the work-queue kernel (the default dispatch for this image is patch refill)
 cfg = fr.Config.new(fr.Algo.Julia)
 cfg.width = cfg.height = 16384
 cfg.iterations = 4096
