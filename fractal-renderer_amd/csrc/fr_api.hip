@@ -316,11 +316,6 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
     p.queue_minrun = o.refill_minrun < 0 ? 8u : (uint32_t)o.refill_minrun;
     p.queue_want = o.refill_quit16 < 0 ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
-    static const uint32_t env_flags = [] {
-        const char *e = getenv("FR_DEBUG_FLAGS"); /* tuning experiments only; results are then NOT images */
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    p.debug_flags = env_flags;
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
     /* the colour filter's constants (fr_kernels.hip: colour_outside_filtered) and the conditions under

@@ -53,7 +53,6 @@ struct fr_kparams {
     /* work-queue kernel: while more pixels wait, an episode ends once `queue_want` lanes have finished and
      * `queue_minrun` iterations were done */
     uint32_t queue_minrun, queue_want;
-    uint32_t debug_flags; /* tuning experiments (FR_DEBUG_FLAGS): 1 = the work-queue kernel skips its pixel stores */
     /* exact periodicity shortcut (refilling kernel, scaled loops): an orbit found bitwise back at an
      * earlier state is fast-forwarded to the cap instead of being iterated there; 0 = off */
     uint32_t cycle_shortcut;

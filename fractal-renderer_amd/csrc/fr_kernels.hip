@@ -1306,8 +1306,7 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
             const double dist = sizeof(T) == 8 ? (double)(r2 + i2) : zre * zre + zim * zim; /* pos.squared_distance(), :214 */
             uint8_t rgb[3];
             colour_of(cc, dist, iters, tab, s_pal, rgb);
-            if (!(kp->debug_flags & 1u) || rgb[0] == 77) /* experiment: what do the stores cost? */
-                store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[e], q_px[e], rgb);
+            store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[e], q_px[e], rgb);
         }
         tr_colour++;
         __syncthreads();
