@@ -344,6 +344,18 @@ def run_single(args, torch, fr, lib, native):
             "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2),
             "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
         }
+        # Algo::BarnsleyFern, Config::new(fern)'s own size and point count, into a host buffer
+        fcfg = fr.Config.new(fr.Algo.BarnsleyFern)
+        fr.get_image_fern(fcfg, 1, 1)
+        tf = time.perf_counter()
+        for k in range(5):
+            fr.get_image_fern(fcfg, 1, 2 + k)
+        fern_ms = (time.perf_counter() - tf) / 5 * 1e3
+        out["other_configs"]["fern"] = {
+            "workload": "barnsley fern %dx%d, %d points, threads=1 (Config::new(Algo::BarnsleyFern)), host buffer" % (
+                fcfg.width, fcfg.height, fcfg.iterations),
+            "ms_per_call": fern_ms, "value": fcfg.iterations / (fern_ms * 1e-3), "unit": "points/s",
+            "note": "chaos game on the GPU (fr_render_fern_rgb8); not part of the headline metric"}
         img = sg.render(cfg, prec)  # the shared device buffer held the other configs meanwhile
         torch.cuda.synchronize(device)
 
@@ -596,7 +608,13 @@ def main():
         _native.check(lib.fr_set_refill_policy(mr, q16))
     if launched:
         args.gpus = world
-        run_distributed(args, torch, fr, lib, _native, world, rank, local_rank)
+        try:
+            run_distributed(args, torch, fr, lib, _native, world, rank, local_rank)
+        except Exception as e:  # noqa: BLE001  (leave a parsable line behind, then fail loudly)
+            if rank == 0:
+                print(json.dumps({"metric": "pixel_iterations_per_sec", "value": None, "unit": "pixel-iterations/s",
+                                  "n_gpus": world, "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
+            raise
     elif args.gpus > 1:
         run_in_library(args, torch, fr, lib, _native)
     else:

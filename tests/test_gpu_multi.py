@@ -247,3 +247,33 @@ def test_last_kernel_name_reports_what_ran(fr, lib):
             assert ms.value > 0
     finally:
         _native.check(lib.fr_set_profiling(0))
+
+
+def _bench(args):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_plain_gpus_n_without_a_launcher():
+    """`python3 bench.py --gpus N` from a plain shell: on a box with fewer than N GPUs it prints a JSON line with an
+    error field and exits 0; with --logical it drives N logical devices through fr_init_devices, and its two
+    variants (gathered in HBM, DMA'd to the host buffer) produce the same bytes."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        d = _bench(["--gpus", "2"])
+        assert d["value"] is None and d["n_gpus"] == 2 and "needs 2 devices" in d["error"]
+    d = _bench(["--gpus", "3", "--logical", "--size", "3072", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 3 and d["value"] > 1e9 and d["scaling"] == "strong"
+    assert d["config"]["logical_devices_on_one_gpu"] is True and "ONE process" in d["config"]["partition"]
+    assert len(d["per_device_kernel_ms"]) == 3 and all(ms > 0 for ms in d["per_device_kernel_ms"])
+    assert d["host_buffer_variant"]["bytes_identical_to_gathered_image"] is True
+    assert 0 < d["roofline"]["frac"] < 1

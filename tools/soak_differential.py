@@ -18,10 +18,14 @@ from fractal_renderer_amd import _native  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 big = len(sys.argv) > 2 and sys.argv[2] == "big"
 base = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000  # large images: default dispatch reaches the 7-tile kernels
+import torch  # noqa: E402,F401  (before the library: INTEGRATION.md §4)
+
 fr.init(0)
+fr.init_devices([0, 0, 0])  # three logical devices on this GPU: the multi-device path joins the soak
 lib = _native.load()
 t0 = time.time()
 bad = 0
+libm_diff = 0
 for seed in range(n):
     rng = np.random.default_rng(base + seed)
     ocfg = T._random_config(rng)
@@ -34,14 +38,20 @@ for seed in range(n):
     cfg = fr.Config.from_buffer_copy(bytes(ocfg))
     f32 = rng.random() < 0.35
     op, fp = (O.F32, fr.Precision.F32) if f32 else (O.F64, fr.Precision.F64)
-    knobs = (int(rng.choice([0, 1, 2, 4, 8, 9, 9, 808, 1604, 3202, 6401])), int(rng.choice([-1, -1, 0, 2, 4])),
-             int(rng.random() < 0.7), int(rng.random() < 0.5))
+    knobs = (int(rng.choice([0, 1, 2, 4, 8, 9, 9, 10, 10, 10, 808, 1604, 3202, 6401])), int(rng.choice([-1, -1, 0, 2, 4])),
+             int(rng.random() < 0.7), int(rng.random() < 0.5), int(rng.random() < 0.7))
     lib.fr_set_tile(knobs[0]); lib.fr_set_loop_mode(knobs[1]); lib.fr_set_palette(knobs[2]); lib.fr_set_cycle_shortcut(knobs[3])
+    lib.fr_set_colour_filter(knobs[4])
     z, it = fr.escape_rows(cfg, precision=fp)
     wz, wit = O.escape_rows(ocfg, op)
     img, want = fr.get_image(cfg, fp), T.oracle_image(ocfg, op)
     checks = dict(iters=np.array_equal(it, wit), z=T.same_f64(z, wz), image=np.array_equal(img, want),
                   count=fr.count_iterations(cfg, precision=fp)[0] == O.count_iterations(ocfg, op))
+    if seed % 5 == 0:  # the one-process multi-device path, into a host buffer
+        checks["multi"] = np.array_equal(fr.get_image_multi(cfg, fp, int(rng.choice([8, 16, 64, 0]))), want)
+    if not np.array_equal(T.oracle_image(ocfg, op, soft=False), want):
+        libm_diff += 1  # the platform libm and the software log2 disagree on an output byte (never seen so far)
+        print("NOTE seed", seed, "libm and software log2 give different bytes", bytes(ocfg).hex(), flush=True)
     if not all(checks.values()):
         bad += 1
         print("MISMATCH seed", seed, knobs, "f32" if f32 else "f64", checks, bytes(ocfg).hex(), flush=True)
@@ -52,5 +62,5 @@ for seed in range(n):
                 it[d[0][0], d[0][1]], np.array_equal(fr.get_image(cfg, fp), want)), flush=True)
     if seed % 50 == 49:
         print("%d configs, %d mismatches, %.0f s" % (seed + 1, bad, time.time() - t0), flush=True)
-print("done: %d configs, %d mismatches" % (n, bad))
+print("done: %d configs, %d mismatches, %d configs where libm and the software log2 differ in a byte" % (n, bad, libm_diff))
 sys.exit(1 if bad else 0)
