@@ -69,7 +69,7 @@ struct Ctx {
     int hip_device = -1;
     std::mutex mu; /* serialises the host-buffer entry points (they share streams + scratch) */
     hipStream_t stream = nullptr;      /* kernels of the host-buffer entry points */
-    hipStream_t stream2 = nullptr;     /* multi-device: chunk kernels alternate between stream / stream2 */
+    hipStream_t stream2 = nullptr;     /* band / chunk kernels alternate between stream and stream2 */
     hipStream_t copy_stream = nullptr; /* D2H / peer copies, overlapped with the next band's kernel */
     std::vector<hipEvent_t> events;
     Scratch rgb, z, iters, misc;

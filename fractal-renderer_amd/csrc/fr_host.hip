@@ -283,7 +283,7 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     if (trace && hipEventCreate(&t_zero) == hipSuccess) (void)hipEventRecord(t_zero, ctx.stream);
     for (size_t i = 0; i < order.size() && rc == FR_OK && err == hipSuccess; i++) {
         const Band &bd = bands[order[i]];
-        hipStream_t st = (i & 1) ? ctx.stream2 : ctx.stream;
+        hipStream_t st = (i & 1) ? ctx.stream2 : ctx.stream; /* three streams measured worse: the first band finishes later */
         rc = render_on(st, bd.ya, bd.yb, scratch + bd.a);
         if (rc != FR_OK) break;
         hipEvent_t e;
@@ -341,7 +341,7 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     const double t_enqueued = now_ms();
     /* always drain both streams and unpin before returning, error or not */
     hipError_t e1 = hipStreamSynchronize(ctx.stream);
-    hipError_t e1b = hipStreamSynchronize(ctx.stream2);
+    const hipError_t e1b = hipStreamSynchronize(ctx.stream2);
     if (e1 == hipSuccess) e1 = e1b;
     hipError_t e2 = hipStreamSynchronize(ctx.copy_stream);
     const double t_synced = now_ms();
