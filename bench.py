@@ -584,7 +584,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and world > 1
+    # FR_BENCH_DISTRIBUTED=1: take the one-process-per-GPU path even at world size 1 (a one-GPU box then exercises
+    # its process-group set-up, collectives and bookkeeping; tests/test_gpu_multi.py)
+    launched = "RANK" in os.environ and (world > 1 or os.environ.get("FR_BENCH_DISTRIBUTED") == "1")
 
     import torch  # first: the library then shares torch's HIP runtime
 

@@ -277,3 +277,25 @@ def test_bench_plain_gpus_n_without_a_launcher():
     assert len(d["per_device_kernel_ms"]) == 3 and all(ms > 0 for ms in d["per_device_kernel_ms"])
     assert d["host_buffer_variant"]["bytes_identical_to_gathered_image"] is True
     assert 0 < d["roofline"]["frac"] < 1
+
+
+def test_bench_under_the_launcher_at_world_size_one():
+    """The driver's own invocation form — python -m torch.distributed.run ... bench.py --gpus N — with N = 1 and the
+    one-process-per-GPU path forced: RCCL process group on the GPU, barriers, all-reduces, the per-rank roofline
+    launch, the JSON line.  (N > 1 needs N GPUs: the driver's to run.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FR_BENCH_DISTRIBUTED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "4096"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1e9 and "one process per GPU" in d["config"]["partition"]
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"].startswith("escape_strip_kernel<double")
