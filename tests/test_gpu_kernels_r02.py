@@ -264,6 +264,37 @@ def test_full_size_c4_work_queue_kernel(fr, lib, prec_name):
     assert torch.equal(img, exact)
 
 
+@pytest.mark.parametrize("view", ["c2", "c3"])
+def test_full_size_mandelbrot_work_queue_kernel_equals_default(fr, lib, view):
+    """BASELINE C2 and C3 (16384^2; C3: zoom 10^6, 65536 iterations — lanes that run to the cap, patches that hold
+    the im == 0 row) through the work-queue kernel: the same 805 306 368 bytes as the default strip kernel, which
+    test_gpu_parity.py pins against the oracle at these sizes."""
+    import torch
+    from fractal_renderer_amd import _native
+
+    if view == "c2":
+        ocfg = O.cli_config(16384, 16384, iterations=1024)
+    else:
+        ocfg = O.cli_config(16384, 16384, iterations=65536, scale=(1e6, 1e6), pos=(-0.7436447860, 0.1318252536))
+    cfg = to_fr(fr, ocfg)
+    need = 3 * 16384 * 16384
+    s = torch.cuda.current_stream()
+    imgs = []
+    for tile in (0, 10):
+        d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        o = fr.RenderOpts(tile=tile)
+        _native.check(lib.fr_set_profiling(1))
+        _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), 0, 0, 16384, d.data_ptr(), need, s.cuda_stream,
+                                                          C.byref(o)))
+        name = C.create_string_buffer(160)
+        _native.check(lib.fr_last_kernel_name(name, len(name)))
+        _native.check(lib.fr_set_profiling(0))
+        assert name.value.startswith(b"escape_queue_kernel" if tile == 10 else b"escape_strip_kernel"), name.value
+        imgs.append(d)
+    torch.cuda.synchronize()
+    assert torch.equal(imgs[0], imgs[1])
+
+
 # ---- the scaled loop at the edges of its admissible range ---------------------------------------------
 
 
