@@ -14,8 +14,9 @@
  *                                ncclSend / ncclRecv on a communicator from ncclCommInitAll (RCCL).
  *
  * A device renders several of its blocks per kernel launch ("chunk": big chunks first — launches of
- * >= 1024 rows run at the single-launch rate — then a geometric tail 4, 2, 1 so that only one block's
- * bytes remain to be moved when the last kernel ends), chunks alternate between two streams so that a
+ * >= 1024 rows run at the single-launch rate, but never more than a quarter of the device's blocks — then
+ * a geometric tail 4, 2, 1 so that only one block's bytes remain to be moved when the last kernel ends),
+ * chunks alternate between two streams so that a
  * kernel's tail overlaps the next kernel's start, and chunk c is on the wire while chunk c+1 renders.
  */
 #include <dlfcn.h>
@@ -171,10 +172,13 @@ thread_local fr_multi_stats tl_stats;
 
 /* Local block index ranges [j0, j1) a device renders per launch (see the file header). */
 std::vector<std::pair<uint32_t, uint32_t>> chunk_schedule(uint32_t nb) {
+    /* at most a quarter of the device's blocks per launch: its transfer takes about as long as its rendering
+     * (both scale as 1/N), so the link has to start early and stay busy */
+    const uint32_t cap = std::max(1u, std::min(kMaxChunkBlocks, nb / 4));
     std::vector<uint32_t> sizes;
     uint32_t rem = nb, s = 1;
     while (rem > 0) {
-        const uint32_t t = std::min(std::min(s, rem), kMaxChunkBlocks);
+        const uint32_t t = std::min(std::min(s, rem), cap);
         sizes.push_back(t);
         rem -= t;
         s *= 2;

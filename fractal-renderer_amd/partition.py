@@ -33,10 +33,14 @@ MAX_CHUNK_BLOCKS = 8     # blocks per launch (2048 rows at the default block siz
 def chunk_schedule(nb):
     """Local block index ranges [j0, j1) a rank renders per launch: big chunks first (launches of
     >= 1024 rows run at the single-launch rate; 256-row launches measured 17 % slower), then a
-    geometric tail 4, 2, 1 so that the bytes still to be sent when the last kernel ends are one block."""
+    geometric tail 4, 2, 1 so that the bytes still to be sent when the last kernel ends are one block.
+    A chunk is at most a quarter of the rank's blocks: a rank's transfer takes about as long as its
+    rendering (both scale as 1/N), so the link has to start early and stay busy — with 8 blocks per rank
+    (16384^2 over 8 GPUs) that is 1, 2, 2, 2, 1 rather than 1, 4, 2, 1."""
+    cap = max(1, min(MAX_CHUNK_BLOCKS, nb // 4))
     sizes, rem, s = [], nb, 1
     while rem > 0:
-        t = min(s, rem, MAX_CHUNK_BLOCKS)
+        t = min(s, rem, cap)
         sizes.append(t)
         rem -= t
         s *= 2
