@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--refill", default="", help="tuning: minrun,quit16 of the refilling kernel")
     ap.add_argument("--loop-mode", type=int, default=-1, help="tuning: force the orbit loop form (0, 2, 4)")
     ap.add_argument("--no-colour-filter", action="store_true", help="tuning: always the f64 software log2")
+    ap.add_argument("--colour-filter", type=int, default=1, help="tuning: 1 = f32 then f64 stage (default), 2 = f64 stage only")
     ap.add_argument("--cycle-shortcut", action="store_true",
                     help="measure with the exact periodicity shortcut on (never the headline: it skips iterations)")
     ap.add_argument("--force-blocks", action="store_true",
@@ -602,7 +603,7 @@ def main():
     lib = _native.load()
     _native.check(lib.fr_set_tile(args.tile))
     _native.check(lib.fr_set_loop_mode(args.loop_mode))
-    _native.check(lib.fr_set_colour_filter(0 if args.no_colour_filter else 1))
+    _native.check(lib.fr_set_colour_filter(0 if args.no_colour_filter else args.colour_filter))
     if args.cycle_shortcut:
         _native.check(lib.fr_set_cycle_shortcut(1))
     if args.refill:

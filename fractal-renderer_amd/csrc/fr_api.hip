@@ -125,7 +125,7 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     o.cycle_shortcut = in->cycle_shortcut != 0;
     o.refill_minrun = in->refill_minrun;
     o.refill_quit16 = in->refill_quit16;
-    o.colour_filter = in->colour_filter != 0;
+    o.colour_filter = in->colour_filter == 2 ? 2 : in->colour_filter != 0;
     return FR_OK;
 }
 
@@ -324,7 +324,13 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     const bool filter_ok = o.colour_filter && cfg->smooth && n != 0 && std::isfinite(cfg->exposure) &&
                            std::fabs(p.filt_k) <= 1e100 && cfg->stable_limit >= 0.0;
     p.colour_filter = filter_ok ? 1u : 0u;
-    for (int k = 0; k < 3; k++) p.filt_d[k] = p.prim_f[k] * std::fabs(p.filt_k) * FR_NU_BRACKET * (1.0 + 0x1p-20);
+    const double ak = std::fabs(p.filt_k);
+    p.colour_filter32 = (filter_ok && o.colour_filter == 1 && n < (1u << 24) && ak >= 0x1p-60 && ak <= 0x1p60) ? 1u : 0u;
+    p.filt_k32 = (float)p.filt_k;
+    for (int k = 0; k < 3; k++) {
+        p.filt_d[k] = p.prim_f[k] * ak * FR_NU_BRACKET * (1.0 + 0x1p-20);
+        p.filt_d32[k] = p.colour_filter32 ? std::nextafterf((float)(p.prim_f[k] * ak * FR_NU_BRACKET * (1.0 + 0x1p-10)), INFINITY) : 0.0f;
+    }
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
@@ -984,7 +990,7 @@ int fr_set_palette(int enabled) {
 }
 
 int fr_set_colour_filter(int enabled) {
-    g_colour_filter.store(enabled ? 1 : 0);
+    g_colour_filter.store(enabled == 2 ? 2 : enabled ? 1 : 0); /* 2: the f64 stage only (tests) */
     return FR_OK;
 }
 

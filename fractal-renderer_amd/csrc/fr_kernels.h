@@ -64,6 +64,10 @@ struct fr_kparams {
     uint32_t *work_counter;
     double filt_k;    /* exposure / iterations (any rounding) */
     double filt_d[3]; /* per stored colour field: |field * filt_k| * FR_NU_BRACKET * (1 + 2^-20) */
+    /* the filter's f32 first stage: on only when iterations < 2^24 and 2^-60 <= |filt_k| <= 2^60 */
+    uint32_t colour_filter32;
+    float filt_k32;    /* (float)filt_k */
+    float filt_d32[3]; /* the same half-widths, times (1 + 2^-10), rounded up to f32 */
 };
 
 /* half-width of the colour filter's bracket around its f32 estimate of nu (fr_kernels.hip) */

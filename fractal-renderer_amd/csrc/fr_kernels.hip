@@ -46,6 +46,8 @@ struct ColourConsts {
     uint32_t filter;        /* smooth colouring: try the f32 bracket first (see colour_outside_filtered) */
     double filt_k;          /* exposure / iterations, any rounding */
     double filt_d[3];       /* prim[k] * |filt_k| * FR_NU_BRACKET * (1 + 2^-20): the bracket's half-width in byte units */
+    uint32_t filter32;      /* ... and before that, the same test carried out in f32 */
+    float filt_k32, filt_d32[3], prim32[3];
 };
 
 template <typename P>
@@ -64,6 +66,12 @@ __device__ __forceinline__ ColourConsts make_colour_consts(const P &p) {
     }
     c.filter = p.colour_filter;
     c.filt_k = p.filt_k;
+    c.filter32 = p.colour_filter32;
+    c.filt_k32 = p.filt_k32;
+    for (int k = 0; k < 3; k++) {
+        c.filt_d32[k] = p.filt_d32[k];
+        c.prim32[k] = (float)p.prim[k];
+    }
     return c;
 }
 
@@ -75,6 +83,12 @@ __device__ __forceinline__ ColourConsts make_colour_consts(const P &p) {
 __device__ __forceinline__ uint32_t sat_u8_dev(double v) {
     uint32_t u;
     asm("v_cvt_u32_f64 %0, %1" : "=v"(u) : "v"(v));
+    return u < 255u ? u : 255u;
+}
+
+__device__ __forceinline__ uint32_t sat_u8_dev(float v) { /* the same, from an f32 */
+    uint32_t u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(v));
     return u < 255u ? u : 255u;
 }
 
@@ -115,10 +129,30 @@ __device__ __forceinline__ bool colour_outside_filtered(const ColourConsts &c, d
     const bool in_range = dist >= 2.0 && dist <= 0x1p120;
     const float l1 = __builtin_amdgcn_logf((float)dist);
     const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
+    const int ch[3] = {0, 2, 1}; /* color_multiply's RGB::new(r, b, g) swap, as in colour_multiply() */
+    /* Stage 1, all in f32 (instructions at half the f64 cost): v32 = col * ((iters + 1 - nu32) * K32).  Four f32
+     * roundings and K's own put it within |v| * 2.4e-7 of col * (iters + 1 - nu32) * K, which is within
+     * col * |K| * E of the real value (nu is within E of nu32); the window used is |v32| * 2^-21 + filt_d32 (the
+     * host rounds that term up), twice the relative part, so that the roundings of the window's own ends are
+     * covered too.  (iterations < 2^24 and 2^-60 <= |K| <= 2^60 — the host checks — keep every step exact
+     * enough: iters + 1 converts exactly, nothing under- or overflows.)  A wave whose lanes all pass is done;
+     * about one wave in fifty is not and goes on to stage 2. */
+    if (c.filter32) {
+        const float m32 = ((float)(iters_u + 1u) - nu32) * c.filt_k32;
+        bool same32 = in_range;
+        for (int k = 0; k < 3; k++) {
+            const float v = c.prim32[ch[k]] * m32;
+            const float w = __builtin_fmaf(__builtin_fabsf(v), 0x1p-21f, c.filt_d32[ch[k]]);
+            const uint32_t lo = sat_u8_dev(v - w), hi = sat_u8_dev(v + w);
+            same32 = same32 && lo == hi;
+            out[k] = (uint8_t)lo;
+        }
+        if (__ballot(!same32) == 0ull) return true;
+    }
+    /* Stage 2: the same test with the arithmetic after nu32 in f64 (window: |v| * 2^-46 + filt_d) */
     const double it2 = ((double)iters_u + 1.0) - (double)nu32; /* iters + 1 is exact */
     const double m = it2 * c.filt_k;
     bool same = in_range;
-    const int ch[3] = {0, 2, 1}; /* color_multiply's RGB::new(r, b, g) swap, as in colour_multiply() */
     for (int k = 0; k < 3; k++) {
         const double v = c.prim[ch[k]] * m;
         const double w = __builtin_fma(__builtin_fabs(v), 0x1p-46, c.filt_d[ch[k]]);

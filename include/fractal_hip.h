@@ -325,7 +325,9 @@ int fr_set_palette(int enabled);
  * the filter on (default) the kernel first brackets that value with the hardware's f32 log and a
  * proven error bound, evaluates the rest of the colour map in f64 at both ends of the bracket and
  * keeps the bytes if they agree (the map is monotone); only pixels whose bracket straddles a byte
- * boundary take the full f64 software log2.  Same bytes either way (tests compare them). */
+ * boundary take the full f64 software log2.  1 (default) first makes the same test in f32 arithmetic, with a
+ * correspondingly wider window, and goes to f64 only for the waves that fail it; 2 = the f64 test only;
+ * 0 = always the software log2.  Same bytes in all three (tests compare them). */
 int fr_set_colour_filter(int enabled);
 
 /* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled

@@ -113,6 +113,10 @@ FILTER_CASES = [
     dict(width=400, height=300, iterations=40, exposure=float("inf")),   # filter must switch itself off
     dict(width=400, height=300, iterations=40, exposure=float("nan")),
     dict(width=200, height=100, iterations=0),
+    dict(width=400, height=300, iterations=300, exposure=1e-20),      # |K| below the f32 stage's range
+    dict(width=400, height=300, iterations=300, exposure=1e25),       # ... and above it
+    dict(width=400, height=300, iterations=2 ** 24 + 5, limit=2.0, scale=(0.05, 0.05), pos=(3.0, 3.0)),  # cap >= 2^24: escapes at once
+    dict(width=640, height=480, iterations=16, exposure=255.0, primary_color=(255, 255, 255)),  # steep: many near-boundary values
 ]
 
 
@@ -125,14 +129,16 @@ def test_colour_filter_gives_the_exact_paths_bytes(fr, case):
     want = O.get_image(ocfg)  # libm log2: what the reference calls
     for prec in (fr.Precision.F64, fr.Precision.F32):
         w32 = want if prec == fr.Precision.F64 else O.get_image(ocfg, O.F32)
-        on = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=1))
-        off = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=0))
-        assert np.array_equal(on, off), (case, prec)
+        on = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=1))   # f32 stage, then f64 stage
+        f64_only = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=2))
+        off = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(colour_filter=0))  # always the software log2
+        assert np.array_equal(on, off) and np.array_equal(f64_only, off), (case, prec)
         assert np.array_equal(on, w32), (case, prec)
 
 
 def test_colour_filter_full_size_c2_identical(fr, lib):
-    """BASELINE C2 (16384^2): filter on and off give the same 805 306 368 bytes."""
+    """BASELINE C2 (16384^2): the filter's three settings (f32 + f64 stages, f64 stage only, off) give the same
+    805 306 368 bytes."""
     import torch
     from fractal_renderer_amd import _native
 
@@ -140,14 +146,14 @@ def test_colour_filter_full_size_c2_identical(fr, lib):
     need = 3 * 16384 * 16384
     s = torch.cuda.current_stream()
     imgs = []
-    for flt in (1, 0):
+    for flt in (1, 2, 0):
         d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
         o = fr.RenderOpts(colour_filter=flt)
         _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), 0, 0, 16384, d.data_ptr(), need, s.cuda_stream,
                                                           C.byref(o)))
         imgs.append(d)
     torch.cuda.synchronize()
-    assert torch.equal(imgs[0], imgs[1])
+    assert torch.equal(imgs[0], imgs[2]) and torch.equal(imgs[1], imgs[2])
 
 
 # ---- the work-queue kernel (tile = 10) --------------------------------------------------------------
