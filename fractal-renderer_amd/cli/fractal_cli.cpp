@@ -7,13 +7,18 @@
 //       -Lfractal-renderer_amd -lfractal_hip -Wl,-rpath,$PWD/fractal-renderer_amd -o fractal_cli
 //   ./fractal_cli 3000 3000 -i 1024 -s 1000000 -x -0.7436447860 -y 0.1318252536 -o zoom
 //
-// Not handled here (by design): -a fern (random IFS, reference CPU code), --gui, --open.
+// Extensions (no counterpart upstream): --f32; --devices 0,1,... (spread the image over several GPUs);
+// for -a fern: --threads N (the rayon thread count being stood in for; default: this machine's hardware
+// threads, what rayon would use) and --seed N (default: from the OS, as the reference seeds from entropy).
+// Not handled here (by design): --gui, --open.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <optional>
+#include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fractal.hpp"
@@ -60,7 +65,8 @@ int main(int argc, char **argv) {
     // defaults: src/lib.rs:34-164
     std::string width = "750", height = "500", limit = "65536", stable_limit = "2", pos_y = "0", scale = "0.4",
                 exposure = "5", filename = "output", algo_s = "mandelbrot", color_weight = "0.01";
-    std::optional<std::string> iterations, pos_x, scale_x, scale_y, primary, secondary, julia_re, julia_im;
+    std::optional<std::string> iterations, pos_x, scale_x, scale_y, primary, secondary, julia_re, julia_im, devices, threads_s,
+        seed_s;
     bool disable_inside = false, unsmooth = false, f32 = false, quiet = false;
     std::vector<std::string> positionals;
 
@@ -89,6 +95,9 @@ int main(int argc, char **argv) {
         else if (a == "--julia-imaginary") julia_im = value(i, "--julia-imaginary");
         else if (a == "-w" || a == "--color-weight") color_weight = value(i, "-w");
         else if (a == "--f32") f32 = true;       // this build's extension (no counterpart upstream)
+        else if (a == "--devices") devices = value(i, "--devices");
+        else if (a == "--threads") threads_s = value(i, "--threads");
+        else if (a == "--seed") seed_s = value(i, "--seed");
         else if (a == "--quiet") quiet = true;
         else if (a == "--open" || a == "-g" || a == "--gui") die(a + " is not supported by this front end");
         else if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9') && a[1] != '.') die("unknown flag " + a);
@@ -104,7 +113,7 @@ int main(int argc, char **argv) {
     Algo algo;
     if (al == "mandelbrot") algo = Algo::Mandelbrot;
     else if (al == "julia") algo = Algo::Julia;
-    else if (al == "fern" || al == "barnsleyfern") die("-a fern is the reference's CPU path (random IFS); not part of this library");
+    else if (al == "fern" || al == "barnsleyfern") algo = Algo::BarnsleyFern;
     else die("invalid algorithm name");
     if (algo == Algo::Julia && (!julia_re || !julia_im)) die("--julia-real and --julia-imaginary are required with -a julia");
     if ((scale_x || scale_y) && scale != "0.4") die("--scale conflicts with --scale-x/--scale-y");
@@ -116,7 +125,7 @@ int main(int argc, char **argv) {
     if (iterations) cfg.iterations = to_u32(*iterations, "iterations");
     cfg.limit = to_f64(limit, "limit");
     cfg.stable_limit = to_f64(stable_limit, "stable-limit");
-    cfg.pos.re = to_f64(pos_x ? *pos_x : (algo == Algo::Julia ? "0" : "-0.6"), "-x");
+    cfg.pos.re = to_f64(pos_x ? *pos_x : (algo == Algo::Julia ? "0" : "-0.6"), "-x"); /* src/lib.rs:66-72: 0 only for julia, so -0.6 for the fern too */
     cfg.pos.im = to_f64(pos_y, "-y");
     cfg.scale.re = to_f64(scale_x ? *scale_x : scale, "scale");
     cfg.scale.im = to_f64(scale_y ? *scale_y : scale, "scale");
@@ -138,10 +147,36 @@ int main(int argc, char **argv) {
     }
 
     try {
-        std::vector<RGB> image(static_cast<size_t>(cfg.width) * cfg.height);
+        if (devices) {
+            std::vector<int> list;
+            size_t pos = 0;
+            while (pos <= devices->size()) {
+                const size_t comma = devices->find(',', pos);
+                const std::string part = devices->substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                list.push_back(static_cast<int>(to_u32(part, "--devices")));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+            use_devices(list);
+        }
+        std::vector<RGB> image;
         const auto t0 = std::chrono::steady_clock::now();
-        check(fr_render_rows_rgb8(&cfg, f32 ? FR_PRECISION_F32 : FR_PRECISION_F64, 0, cfg.height,
-                                  reinterpret_cast<uint8_t *>(image.data()), image.size() * 3));
+        if (algo == Algo::BarnsleyFern) {
+            uint32_t threads = threads_s ? to_u32(*threads_s, "--threads") : std::thread::hardware_concurrency();
+            if (threads == 0) threads = 1;
+            uint64_t seed = 0;
+            if (seed_s) {
+                char *end = nullptr;
+                seed = std::strtoull(seed_s->c_str(), &end, 10);
+                if (end == seed_s->c_str() || *end != '\0') die("invalid value for --seed: " + *seed_s);
+            } else {
+                std::random_device rd;
+                seed = (static_cast<uint64_t>(rd()) << 32) | rd();
+            }
+            image = get_image_fern(cfg, threads, seed);
+        } else {
+            image = get_image(cfg, f32 ? FR_PRECISION_F32 : FR_PRECISION_F64);
+        }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         const std::string path = filename + ".ppm";  // the reference appends ".avif" (src/lib.rs:192-195)
         std::FILE *f = std::fopen(path.c_str(), "wb");

@@ -10,7 +10,8 @@
 //   calc::Config, Config::new      calc/src/lib.rs:21-69     fractal::Config, Config::make(algo)
 //   calc::recursive                calc/src/lib.rs:245-257   fractal::recursive
 //   calc::get_recursive_pixel      calc/src/lib.rs:199-235   fractal::get_recursive_pixel
-//   get_image                      src/lib.rs:253-270        fractal::get_image
+//   get_image                      src/lib.rs:253-270        fractal::get_image (one GPU, or the set chosen with use_devices)
+//   get_image, BarnsleyFern arm    src/lib.rs:271-319,417-463  fractal::get_image_fern
 //
 // The reference's functions are infallible and panic on misuse; here a failing C-ABI call throws
 // fractal::Error (there is no CPU fallback to fall back to).
@@ -83,11 +84,34 @@ inline RGB get_recursive_pixel(const Config &config, uint32_t x, uint32_t y) {
     return RGB{out.r, out.g, out.b};
 }
 
-// get_image(&Config) -> Vec<RGB> — src/lib.rs:253-270 (Mandelbrot | Julia arm; the fern arm is a
-// different algorithm and stays with the reference's CPU code).
-inline std::vector<RGB> get_image(const Config &config) {
+// Spread get_image over several GPUs (the reference spreads its rows over every core, src/lib.rs:256-258):
+// HIP device indices; an index may repeat.  One device (or never calling this) = the single-GPU path.
+inline int &multi_devices() {
+    static int n = 0;
+    return n;
+}
+inline void use_devices(const std::vector<int> &devices) {
+    check(fr_init_devices(devices.data(), static_cast<int>(devices.size())));
+    multi_devices() = static_cast<int>(devices.size());
+}
+
+// get_image(&Config) -> Vec<RGB> — src/lib.rs:253-270 (Mandelbrot | Julia arm)
+inline std::vector<RGB> get_image(const Config &config, int precision = FR_PRECISION_F64) {
     std::vector<RGB> image(static_cast<size_t>(config.width) * config.height);
-    check(fr_render_rgb8(&config, reinterpret_cast<uint8_t *>(image.data()), image.size() * sizeof(RGB)));
+    uint8_t *out = reinterpret_cast<uint8_t *>(image.data());
+    if (multi_devices() > 1)
+        check(fr_render_rgb8_multi(&config, precision, 0, out, image.size() * sizeof(RGB)));
+    else
+        check(fr_render_rows_rgb8(&config, precision, 0, config.height, out, image.size() * sizeof(RGB)));
+    return image;
+}
+
+// get_image's Algo::BarnsleyFern arm — src/lib.rs:271-319 + fern() :417-463.  threads = what
+// rayon::current_num_threads() is on the machine being stood in for (the reference returns ONE thread's image of
+// iterations / threads points); seed replaces SmallRng::from_entropy() (src/lib.rs:428).
+inline std::vector<RGB> get_image_fern(const Config &config, uint32_t threads, uint64_t seed) {
+    std::vector<RGB> image(static_cast<size_t>(config.width) * config.height);
+    check(fr_render_fern_rgb8(&config, threads, seed, 0, reinterpret_cast<uint8_t *>(image.data()), image.size() * sizeof(RGB)));
     return image;
 }
 

@@ -107,6 +107,31 @@ def test_cli_reproduces_reference_command_lines(tmp_path):
         assert np.array_equal(img, want), args
 
 
+@pytest.mark.gpu
+def test_cli_fern_and_multi_device(tmp_path):
+    """-a fern through the CLI (seeded: --threads 4 --seed 7) against the oracle's restatement with the same
+    RNG and the library's automatic walker count; and a Mandelbrot command line over --devices 0,0,0."""
+    import numpy as np
+
+    import oracle_lib as O
+
+    build_cli()
+    out = str(tmp_path / "fern")
+    r = subprocess.run([CLI_EXE, "-a", "fern", "--threads", "4", "--seed", "7", "-i", "200000", "400", "300", "-o", out, "--quiet"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    # what get_options builds for -a fern (src/lib.rs:168-226): Config::new(fern) + CLI defaults (x = -0.6, ...)
+    ocfg = O.cli_config(400, 300, O.BARNSLEY_FERN, iterations=200000)
+    steps = 200000 // 4
+    walkers = max(1, min(65536, steps // 256))
+    assert np.array_equal(_read_ppm(out + ".ppm"), O.fern_image(ocfg, 4, 7, walkers))
+    out = str(tmp_path / "multi")
+    r = subprocess.run([CLI_EXE, "--devices", "0,0,0", "-i", "300", "777", "333", "-o", out, "--quiet"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(_read_ppm(out + ".ppm"), O.get_image(O.cli_config(777, 333, iterations=300)))
+
+
 C_EXE = os.path.join(ROOT, "tests", "cpp", "test_c_abi")
 
 
