@@ -443,6 +443,13 @@ def run_in_library(args, torch, fr, lib, native):
     def step():
         native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), int(prec), args.block_rows, gather, d_img.data_ptr(), need))
 
+    gather_note = None
+    if gather == native.FR_GATHER_RCCL:
+        try:
+            step()
+        except native.FractalHipError as e:  # no usable RCCL in this process: the peer-DMA gather does the same job
+            gather_note = "RCCL gather unavailable (%s); fell back to peer-to-peer DMA" % e
+            gather = native.FR_GATHER_PEER_COPY
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -490,6 +497,8 @@ def run_in_library(args, torch, fr, lib, native):
                                 "note": "fr_render_rgb8_multi: each device DMAs its blocks straight to their place in the "
                                         "caller's pinned host buffer over its own PCIe link; resident buffer"},
     }
+    if gather_note:
+        out["config"]["exchange_note"] = gather_note
     if logical:
         out["note"] = "logical devices share ONE GPU: this line checks the plumbing and is not a scaling measurement"
     print(json.dumps(out), flush=True)
