@@ -291,20 +291,24 @@ int fr_count_iterations(const fr_config *cfg, int precision, uint32_t y0, uint32
 int fr_set_profiling(int enabled);
 int fr_last_kernel_ms(float *ms);
 /* Name of the render kernel the calling thread's last device-pointer render launched (profiling on),
- * e.g. "escape_strip_kernel<double, RGB, 7>": bench.py reports what actually ran. */
+ * e.g. "escape_strip_kernel<double, 7 tiles>": bench.py reports what actually ran. */
 int fr_last_kernel_name(char *buf, size_t buf_len);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
  * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
  * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
  * 9 = 7-tile strips with lane refill (the default for large Julia images);
+ * 10 = the work-queue kernel (persistent waves drawing 64x32-pixel patches from a device-wide counter, unchecked
+ *      blocks of iterations, results finished and coloured 64 at a time; RGB renders of an escape-time algorithm
+ *      whose loop plan allows the scaled form — otherwise it acts as 9);
  * 6401, 3202, 1604, 808 = the 4-wave-workgroup kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave
  * pixel footprint. */
 int fr_set_tile(int tile);
 
-/* Policy of the lane-refilling kernel (tuning studies): an orbit episode may end early, so that
- * idle lanes get new pixels, once quit16/16 of its running lanes have finished and at least `minrun`
- * iterations were done.  Does not affect results. */
+/* Policy of the lane-refilling kernels (tuning studies): an orbit episode may end early, so that
+ * idle lanes get new pixels, once quit16/16 of its running lanes (work-queue kernel: of the wave's 64 lanes)
+ * have finished and at least `minrun` iterations were done.  -1 = the kernel's own measured default.  Does not
+ * affect results. */
 int fr_set_refill_policy(int minrun, int quit16);
 
 /* Exact periodicity shortcut, OFF by default.  When on, large images are rendered by the refilling
