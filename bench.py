@@ -214,13 +214,13 @@ class SingleGpu:
                 "total": total, "kernel": name.value.decode(), "image": img}
 
 
-def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup):
+def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup, edge=16384):
     prec = fr.Precision.F32 if prec_name == "f32" else fr.Precision.F64
-    cfg = make_config(fr, view, 16384, iterations)
+    cfg = make_config(fr, view, edge, iterations)
     m = sg.measure(cfg, prec, steps, warmup)
     pixels = cfg.width * cfg.height
     return {
-        "workload": "%s 16384x16384 max_iter=%d %s view=%s (BASELINE %s)" % (VIEWS[view][0], iterations, prec_name, view, name),
+        "workload": "%s %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (VIEWS[view][0], edge, edge, iterations, prec_name, view, name),
         "value": m["total"] * steps / m["dt"], "unit": "pixel-iterations/s", "steps": steps, "warmup": warmup,
         "ms_per_step": m["ms_per_step"], "dtype": prec_name, "pixel_iterations_per_image": m["total"],
         "mean_iterations_per_pixel": m["total"] / pixels,
@@ -345,6 +345,14 @@ def run_single(args, torch, fr, lib, native):
             "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2),
             "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
         }
+        # C5's image (65536^2, 12.9 GB) on ONE device: what each of 8 GPUs would share out; the 8-GPU run is the driver's
+        try:
+            out["other_configs"]["C5_image_on_one_gpu"] = other_config_line(sg, fr, "C5's image, one GPU", "default", 1024, "f64", 2, 1,
+                                                                            edge=65536)
+        except Exception as e:  # noqa: BLE001  (a smaller card: not an error of the headline)
+            out["other_configs"]["C5_image_on_one_gpu"] = {"error": repr(e)}
+        sg.image = None
+        torch.cuda.empty_cache()
         # Algo::BarnsleyFern, Config::new(fern)'s own size and point count, into a host buffer
         fcfg = fr.Config.new(fr.Algo.BarnsleyFern)
         fr.get_image_fern(fcfg, 1, 1)
