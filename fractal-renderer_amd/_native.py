@@ -198,6 +198,7 @@ PROTOTYPES = {
     "fr_set_refill_policy": (C.c_int, [C.c_int, C.c_int]),
     "fr_debug_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "fr_debug_set_queue_trace": (C.c_int, [C.c_void_p]),
+    "fr_debug_set_two_pass_capacity": (C.c_int, [C.c_uint32]),
 }
 
 _lib = None

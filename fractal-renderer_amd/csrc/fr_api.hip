@@ -51,10 +51,11 @@ std::atomic<int> g_refill_minrun{-1}, g_refill_quit16{-1}; /* -1: each kernel's 
 std::atomic<int> g_loop_mode{-1}; /* -1 auto, 0 unscaled, 2 / 4 scaled with that check interval */
 std::atomic<int> g_colour_filter{1};
 std::atomic<unsigned long long *> g_queue_trace{nullptr}; /* tuning aid, see fr_debug_set_queue_trace */
+std::atomic<uint32_t> g_two_pass_list_entries{0};          /* test aid, see fr_debug_set_two_pass_capacity */
 
 bool valid_tile(int tile) {
     switch (tile) {
-    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 6401: case 3202: case 1604: case 808:
+    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 6401: case 3202: case 1604: case 808:
         return true;
     default:
         return false;
@@ -114,7 +115,7 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     o = default_opts();
     if (!in) return FR_OK;
     if (in->size < sizeof(fr_render_opts)) return fail(FR_ERR_INVALID_ARGUMENT, "fr_render_opts.size is too small (use fr_render_opts_init)");
-    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 6401, 3202, 1604 or 808");
+    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 11, 6401, 3202, 1604 or 808");
     if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
     if (in->refill_minrun < -1 || in->refill_quit16 < -1 || in->refill_quit16 == 0 || in->refill_quit16 > 16)
@@ -163,6 +164,11 @@ void Ctx::destroy() {
             if (ps.done) (void)hipEventDestroy(ps.done);
             ps = PaletteSlot();
         }
+        for (SurvSlot &ss : surv_slots) {
+            if (ss.dev) (void)hipFree(ss.dev);
+            if (ss.done) (void)hipEventDestroy(ss.done);
+            ss = SurvSlot();
+        }
     }
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -203,7 +209,7 @@ int Ctx::acquire_palette(PaletteSlot **out) {
         PaletteSlot &s = palette_slots[palette_next++ % kPaletteSlots];
         if (s.busy) continue; /* another thread is between acquire and its event record */
         if (!s.dev) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * (FR_MAX_PALETTE_ENTRIES + 16)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * (FR_MAX_PALETTE_ENTRIES + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE)));
             HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         }
         if (s.pending) {
@@ -222,6 +228,38 @@ void Ctx::release_palette(PaletteSlot *slot, hipStream_t st) {
     if (!slot) return;
     const bool recorded = hipEventRecord(slot->done, st) == hipSuccess;
     if (!recorded) (void)hipStreamSynchronize(st); /* no event to wait on later: wait now */
+    std::lock_guard<std::mutex> lk(palette_mu);
+    slot->pending = recorded;
+    slot->busy = false;
+}
+
+int Ctx::acquire_surv(size_t bytes, SurvSlot **out) {
+    std::lock_guard<std::mutex> lk(palette_mu);
+    for (int tries = 0; tries < kSurvSlots; tries++) {
+        SurvSlot &s = surv_slots[surv_next++ % kSurvSlots];
+        if (s.busy) continue;
+        if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        if (s.pending) {
+            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if three two-pass renders are in flight */
+            s.pending = false;
+        }
+        if (s.cap < bytes) {
+            if (s.dev) HIP_TRY(hipFree(s.dev));
+            s.dev = nullptr, s.cap = 0;
+            HIP_TRY(hipMalloc(&s.dev, bytes));
+            s.cap = bytes;
+        }
+        s.busy = true;
+        *out = &s;
+        return FR_OK;
+    }
+    return fail(FR_ERR_HIP, "no survivor-list slot available");
+}
+
+void Ctx::release_surv(SurvSlot *slot, hipStream_t st) {
+    if (!slot) return;
+    const bool recorded = hipEventRecord(slot->done, st) == hipSuccess;
+    if (!recorded) (void)hipStreamSynchronize(st);
     std::lock_guard<std::mutex> lk(palette_mu);
     slot->pending = recorded;
     slot->busy = false;
@@ -314,8 +352,12 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
      * once 24 lanes are free and 8 iterations were done */
     p.refill_minrun = o.refill_minrun < 0 ? 32u : (uint32_t)o.refill_minrun;
     p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
-    p.queue_minrun = o.refill_minrun < 0 ? 8u : (uint32_t)o.refill_minrun;
-    p.queue_want = o.refill_quit16 < 0 ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
+    p.queue_minrun = (o.refill_minrun < 0 || o.tile == 11) ? 8u : (uint32_t)o.refill_minrun;
+    /* tile 11: minrun = the first pass's episode length, quit16 = the lanes (in 16ths of a wave) a tile must
+     * keep running to stay in the first pass; the second pass keeps its own defaults */
+    p.first_keep = (o.tile == 11 && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
+    p.two_pass_cap = (o.tile == 11 && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
+    p.queue_want = (o.refill_quit16 < 0 || o.tile == 11) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
     /* the colour filter's constants (fr_kernels.hip: colour_outside_filtered) and the conditions under
@@ -424,16 +466,49 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
-    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 10;
-    const bool want_queue = fr_wants_work_queue(p, o.tile);
+    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 11;
+    const bool want_two_pass = fr_wants_two_pass(p, precision, o.tile);
+    const bool want_queue = want_two_pass || fr_wants_work_queue(p, o.tile);
     if (want_palette || want_queue) {
         int rc = ctx.acquire_palette(&slot);
         if (rc != FR_OK) return rc;
     }
-    if (want_queue) { /* the persistent waves' patch counter lives behind the slot's palette words */
-        p.work_counter = slot->dev + FR_MAX_PALETTE_ENTRIES;
-        hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream);
+    SurvSlot *surv = nullptr;
+    if (want_two_pass) {
+        /* room for a quarter of the pixels (C4 leaves a tenth); what does not fit is finished by the first
+         * pass itself, so the size is a matter of speed only */
+        const uint64_t npix = (uint64_t)p.ncols * p.nrows;
+        uint64_t entries = npix / 4;
+        if (entries < 65536) entries = 65536;
+        if (entries > (256ull << 20)) entries = 256ull << 20;
+        uint64_t sub = (entries + FR_SURV_QUEUES - 1) / FR_SURV_QUEUES;
+        if (const uint32_t forced = g_two_pass_list_entries.load()) sub = forced;
+        sub = (sub + FR_SURV_CHUNK - 1) / FR_SURV_CHUNK * FR_SURV_CHUNK;
+        p.surv_sub_capacity = (uint32_t)sub;
+        const fr_two_pass_layout lay = fr_two_pass_bytes(p, precision, p.surv_sub_capacity);
+        int rc = ctx.acquire_surv(lay.total, &surv);
+        if (rc != FR_OK) {
+            ctx.release_palette(slot, stream);
+            return rc;
+        }
+        char *base = static_cast<char *>(surv->dev);
+        p.surv_z = base + lay.z_off;
+        p.surv_pos = reinterpret_cast<uint32_t *>(base + lay.pos_off);
+        p.surv_cnt = reinterpret_cast<uint32_t *>(base + lay.cnt_off);
+        p.surv_c = base + lay.c_off;
+        p.surv_counts = reinterpret_cast<uint32_t *>(base + lay.counts_off);
+        hipError_t e = hipMemsetAsync(p.surv_counts, 0, FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE * sizeof(uint32_t), stream);
         if (e != hipSuccess) {
+            ctx.release_surv(surv, stream);
+            ctx.release_palette(slot, stream);
+            return fail_hip(e, "hipMemsetAsync(survivor counters)");
+        }
+    }
+    if (want_queue) { /* the persistent waves' claim counters live behind the slot's palette words */
+        p.work_counter = slot->dev + FR_MAX_PALETTE_ENTRIES;
+        hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t) * FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE, stream);
+        if (e != hipSuccess) {
+            ctx.release_surv(surv, stream);
             ctx.release_palette(slot, stream);
             return fail_hip(e, "hipMemsetAsync(work counter)");
         }
@@ -443,6 +518,7 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
         p.palette_entries = cfg->iterations + 1;
         hipError_t e = fr_launch_palette(p, slot->dev, stream);
         if (e != hipSuccess) {
+            ctx.release_surv(surv, stream);
             ctx.release_palette(slot, stream);
             return fail_hip(e, "fr_launch_palette");
         }
@@ -450,9 +526,13 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
     struct SlotGuard {
         Ctx &ctx;
         PaletteSlot *slot;
+        SurvSlot *surv;
         hipStream_t stream;
-        ~SlotGuard() { ctx.release_palette(slot, stream); }
-    } guard{ctx, slot, stream};
+        ~SlotGuard() {
+            ctx.release_surv(surv, stream);
+            ctx.release_palette(slot, stream);
+        }
+    } guard{ctx, slot, surv, stream};
     fr_kout out{};
     out.rgb = static_cast<uint8_t *>(d_out);
     out.trace = g_queue_trace.load();
@@ -966,7 +1046,7 @@ int fr_last_kernel_name(char *buf, size_t buf_len) {
 }
 
 int fr_set_tile(int tile) {
-    if (!valid_tile(tile)) return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 10, 6401, 3202, 1604 or 808");
+    if (!valid_tile(tile)) return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 10, 11, 6401, 3202, 1604 or 808");
     g_tile.store(tile);
     return FR_OK;
 }
@@ -1005,6 +1085,13 @@ int fr_set_loop_mode(int mode) {
  * their start / end time and work counts to; NULL = off */
 int fr_debug_set_queue_trace(void *d_trace) {
     g_queue_trace.store(static_cast<unsigned long long *>(d_trace));
+    return FR_OK;
+}
+
+/* test aid: entries per survivor list of the two-pass render (0 = sized from the image); a tiny value makes
+ * the lists overflow, which the first pass must absorb */
+int fr_debug_set_two_pass_capacity(uint32_t entries_per_list) {
+    g_two_pass_list_entries.store(entries_per_list);
     return FR_OK;
 }
 

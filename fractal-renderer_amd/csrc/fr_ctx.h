@@ -58,12 +58,22 @@ struct Scratch {
  * (no allocation on the render path, usable from any stream of that device).  A slot is handed out
  * only after the event recorded behind its last user has completed. */
 struct PaletteSlot {
-    uint32_t *dev = nullptr; /* FR_MAX_PALETTE_ENTRIES palette words, then the work-queue kernel's counter */
+    uint32_t *dev = nullptr; /* FR_MAX_PALETTE_ENTRIES palette words, then the work-queue kernel's claim counters */
     hipEvent_t done = nullptr;
     bool pending = false; /* `done` was recorded and not yet waited for */
     bool busy = false;    /* a thread is between acquire and its event record */
 };
 constexpr int kPaletteSlots = 16;
+
+/* Survivor lists of the two-pass render (fr_kernels.hip): a ring of three device buffers, grown on demand,
+ * handed out like the palette slots. */
+struct SurvSlot {
+    void *dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false, busy = false;
+};
+constexpr int kSurvSlots = 3;
 
 struct Ctx {
     int hip_device = -1;
@@ -74,8 +84,9 @@ struct Ctx {
     std::vector<hipEvent_t> events;
     Scratch rgb, z, iters, misc;
     PaletteSlot palette_slots[kPaletteSlots];
-    std::mutex palette_mu;
-    unsigned palette_next = 0;
+    SurvSlot surv_slots[kSurvSlots];
+    std::mutex palette_mu; /* guards both rings */
+    unsigned palette_next = 0, surv_next = 0;
 
     int create(int device); /* hipSetDevice + streams; the calling thread stays on `device` */
     void destroy();         /* frees everything (caller made sure nothing is in flight) */
@@ -83,6 +94,8 @@ struct Ctx {
     int event(size_t k, hipEvent_t *out); /* k-th reusable event (created on demand) */
     int acquire_palette(PaletteSlot **out);
     void release_palette(PaletteSlot *slot, hipStream_t stream); /* record + make reusable */
+    int acquire_surv(size_t bytes, SurvSlot **out);
+    void release_surv(SurvSlot *slot, hipStream_t stream);
 };
 
 /* calc::Config -> kernel arguments (the local grid is filled in by the caller) and the loop plan */

@@ -59,8 +59,9 @@ struct fr_kparams {
     /* smooth colouring: bracket log2(log2(sqrt(dist))/2) with the hardware f32 log first and take the
      * f64 software log2 only for pixels whose bracket straddles a byte boundary; 0 = always f64 */
     uint32_t colour_filter;
-    /* work-queue kernel: a device counter, zeroed on the launch stream, from which its persistent waves
-     * draw patches; NULL = that kernel is not available to this launch */
+    /* work-queue kernel: FR_SURV_QUEUES device counters FR_SURV_COUNT_STRIDE words apart, zeroed on the launch
+     * stream, through which its persistent waves claim patches / chunks; NULL = that kernel is not available to
+     * this launch */
     uint32_t *work_counter;
     double filt_k;    /* exposure / iterations (any rounding) */
     double filt_d[3]; /* per stored colour field: |field * filt_k| * FR_NU_BRACKET * (1 + 2^-20) */
@@ -68,7 +69,26 @@ struct fr_kparams {
     uint32_t colour_filter32;
     float filt_k32;    /* (float)filt_k */
     float filt_d32[3]; /* the same half-widths, times (1 + 2^-10), rounded up to f32 */
+    /* two-pass rendering (fr_kernels.hip, "first pass + survivor list"): the first pass runs every pixel
+     * `first_cap` iterations and appends the orbits still going to one of FR_SURV_QUEUES lists in device
+     * memory; the second pass (the work-queue kernel, drawing from those lists) finishes them.
+     * first_cap == 0: not in use.  List q holds entries [q * surv_sub_capacity, (q + 1) * surv_sub_capacity);
+     * its counter (zeroed on the launch stream by the caller) is surv_counts[q * FR_SURV_COUNT_STRIDE] and may
+     * run past the capacity: what did not fit was finished by the first pass itself. */
+    uint32_t first_cap;    /* length of a first-pass episode */
+    uint32_t first_keep;   /* a tile stays in the first pass while at least this many of its lanes are running */
+    uint32_t two_pass_cap; /* the caller's wish for first_cap (0 = the default) */
+    uint32_t surv_sub_capacity;
+    void *surv_z;           /* T[2] per entry: the position after first_cap iterations */
+    uint32_t *surv_pos;     /* uint32[2] per entry: output column, output row */
+    uint32_t *surv_cnt;     /* iterations the entry's pixel has done */
+    void *surv_c;           /* T[2] per entry: c (Mandelbrot; unused for Julia, whose c is julia_set) */
+    uint32_t *surv_counts;
 };
+
+constexpr uint32_t FR_SURV_QUEUES = 64;       /* = the wave size: the second pass scans the counters one per lane */
+constexpr uint32_t FR_SURV_COUNT_STRIDE = 32; /* words between counters: one 128-byte line each */
+constexpr uint32_t FR_SURV_CHUNK = 64;        /* entries a second-pass wave claims at a time: one per lane */
 
 /* half-width of the colour filter's bracket around its f32 estimate of nu (fr_kernels.hip) */
 constexpr double FR_NU_BRACKET = 0x1p-18;
@@ -100,6 +120,15 @@ hipError_t fr_launch_escape(const fr_kparams &p, int precision, int mode, const 
 /* Would fr_launch_escape(p, ..., FR_OUT_RGB, ..., tile) pick the work-queue kernel if p.work_counter were set?
  * (The caller then lends a counter and zeroes it on the launch stream.) */
 bool fr_wants_work_queue(const fr_kparams &p, int tile);
+
+/* Would fr_launch_escape(p, ..., FR_OUT_RGB, ..., tile) render in two passes if the survivor lists were set?
+ * (The caller then lends them — fr_two_pass_bytes() says how large for `entries` per list — and zeroes
+ * surv_counts and work_counter on the launch stream.)  Sets p.first_cap when it answers yes. */
+bool fr_wants_two_pass(fr_kparams &p, int precision, int tile);
+struct fr_two_pass_layout {
+    size_t z_off, pos_off, cnt_off, c_off, counts_off, total; /* byte offsets into one allocation */
+};
+fr_two_pass_layout fr_two_pass_bytes(const fr_kparams &p, int precision, uint32_t sub_capacity);
 
 /* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
  * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */

@@ -840,6 +840,190 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
     }
 }
 
+/* ---- first pass + survivor list (two-pass rendering, part 1) ---------------------------------------
+ *
+ * C4's orbits (a Julia dust: mean 44 iterations, none near the cap of 4096, 58 % of the pixels gone after 8)
+ * are spatially coherent while they are short: an 8x8 tile run only to iteration 128 keeps 91 % of its lanes
+ * busy (to 64: 98 %), against 34 % when it runs until its slowest pixel is done — the waste is all in the
+ * tail.  So the strip kernel's cheap, static, fully fused form takes every pixel the first `first_cap`
+ * iterations; a pixel that has escaped by then (89 % of them at 128) is coloured and stored on the spot,
+ * coalesced, with its tile.  The others — position after first_cap iterations, output position (and c, for
+ * Mandelbrot) — are appended to a list in device memory, which the work-queue kernel (below, SRC = 1) drains
+ * with full waves.  Its per-pixel costs (hand-out, stack, finishing pass with scattered stores) are then paid
+ * by one pixel in ten.
+ *
+ * The list is FR_SURV_QUEUES lists with a counter each (one atomic per tile that has survivors — a million
+ * of them on C4 — would queue up on a single address); a strip appends to the list its position hashes to.
+ * A list that is full is not an error: the lanes that did not get a slot run their orbit to the end right
+ * here, as the strip kernel would have.  Same bytes whichever way a pixel goes: the state after first_cap
+ * iterations is recursive()'s own, and the second pass continues it with recursive()'s own arithmetic. */
+template <typename T>
+struct Pair;
+template <>
+struct Pair<float> {
+    typedef float2 type;
+};
+template <>
+struct Pair<double> {
+    typedef double2 type;
+};
+
+/* Kernel arguments for the COLD parts of a kernel whose hot loop needs the scalar registers: re-read from
+ * the kernel-argument segment where they are used (scalar loads through a pointer the optimiser cannot see
+ * through) instead of being held in SGPRs from the kernel's entry on, as arguments normally are — the ~50
+ * values of the colour map and the addressing overflow the scalar file otherwise, and every use becomes a
+ * v_readlane spill reload (224 of them per tile in this kernel's first version). */
+typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
+#define FR_COLD_PARAMS(NAME)                                                          \
+    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is argument 0 */ \
+    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay where they are written */
+
+template <typename T, int M, int kStripTiles>
+__global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, const fr_kout out) {
+    __shared__ double s_tab[(FR_LOG2_N * 3 * 8 > FR_MAX_PALETTE_ENTRIES * 4 ? FR_LOG2_N * 3 * 8 : FR_MAX_PALETTE_ENTRIES * 4) / 8];
+    typedef typename Pair<T>::type T2;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *s_pal = nullptr;
+    uint32_t row0, tile0, ncols, nrows, r_out;
+    double coord_lane, sim;
+    bool strip_scalable;
+    {
+        FR_COLD_PARAMS(kp);
+        const auto &P = *kp;
+        if (P.palette != nullptr) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_tab);
+            const uint32_t n = P.palette_entries;
+            const uint32_t *src = P.palette;
+            for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
+            s_pal = dst;
+        } else if (P.smooth) {
+            const double *gt = &g_log2_tab[0][0];
+            for (uint32_t k = lane; k < FR_LOG2_N * 3; k += 64) s_tab[k] = gt[k];
+        }
+        __syncthreads();
+        row0 = (blockIdx.y + gridDim.y * blockIdx.z) * 8u;
+        nrows = P.nrows, ncols = P.ncols;
+        if (row0 >= nrows) return;
+        const uint32_t ly = lane >> 3;
+        const double width = (double)P.width, height = (double)P.height;
+        /* the strip's coordinate map, as in escape_strip_kernel: column lanes 0-55, row lanes 56-63 */
+        static_assert(kStripTiles <= 7, "lanes 56-63 are the row lanes");
+        const bool row_lane = lane >= 56;
+        tile0 = blockIdx.x * kStripTiles;
+        const uint32_t block_rows = P.block_rows, y_first = P.y_first, y_stride = P.y_stride;
+        uint32_t coord_u;
+        if (row_lane) {
+            const uint32_t rr = row0 + (lane - 56);
+            coord_u = y_first + (rr / block_rows) * y_stride + rr % block_rows;
+        } else {
+            coord_u = P.x_first + (tile0 * 8u + lane) * P.x_stride;
+        }
+        coord_lane = coord_to_space((double)coord_u, height, row_lane ? 0.5 : (width / height) / 2.0,
+                                    row_lane ? P.pos_im : P.pos_re, row_lane ? P.scale_im : P.scale_re);
+        sim = __shfl(coord_lane, 56 + ly, 64);
+        uint32_t out_row0 = row0;
+        if (P.out_in_place) out_row0 = y_first + (row0 / block_rows) * y_stride + row0 % block_rows;
+        r_out = out_row0 + ly;
+        const bool relevant = lane >= 56 ? (row0 + (lane - 56) < nrows) : (tile0 * 8u + lane < ncols);
+        strip_scalable = coords_admissible<T>(P.algo == 2, P.julia_re, P.julia_im, coord_lane, relevant);
+    }
+    const uint32_t lx = lane & 7u;
+    const uint32_t r = row0 + (lane >> 3);
+    /* what the loops need, held in scalar registers across the strip */
+    const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_keep; /* the host guarantees 0 < k1 < cap */
+    const bool julia = p.algo == 2;
+    const T jre = (T)p.julia_re, jim = (T)p.julia_im;
+    const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
+    const T skip_t = (T)p.skip_t;
+    /* neighbouring strips append to different lists */
+    const uint32_t list = (blockIdx.x + 5u * (row0 >> 3)) & (FR_SURV_QUEUES - 1u);
+
+    for (int k = 0; k < kStripTiles; k++) {
+        const uint32_t col0 = (tile0 + k) * 8u;
+        if (col0 >= ncols) break; /* wave-uniform */
+        const double sre = __shfl(coord_lane, k * 8 + lx, 64);
+        const uint32_t cx = col0 + lx;
+        const bool valid = cx < ncols && r < nrows;
+        T re = (T)sre, im = (T)sim, r2 = 0, i2 = 0;
+        const T cre = julia ? jre : re, cim = julia ? jim : im; /* calc/src/lib.rs:209-210 */
+        uint32_t iters = 0, start = 0;
+        bool slow = valid; /* lanes that run recursive()'s plain loop to the end, from `start` */
+        bool handed_over = false;
+        if (strip_scalable) {
+            /* episodes of k1 iterations for as long as the tile is worth a wave of its own: at least `keep`
+             * lanes still running (a tile inside the set stays here to the cap, at full lanes, exactly as in
+             * the strip kernel); then what is left of it goes to the list, with the iterations it has done */
+            slow = false;
+            bool running = valid;
+            uint32_t done = 0;
+            unsigned long long sm;
+            for (;;) {
+                const uint32_t n = cap - done < k1 ? cap - done : k1;
+                if (running) {
+                    const uint32_t it = orbit_scaled<T, M>(n, re, im, cre, cim, squared, skip_t, r2, i2);
+                    if (it < n) iters = done + it, running = false; /* escaped: (re, im) = `next`, frozen from here on */
+                }
+                done += n;
+                sm = __ballot(running);
+                if (sm == 0ull) break;
+                if (done == cap) { /* no escape within the cap: recursive() returns (iterations, previous) */
+                    if (running) iters = cap;
+                    sm = 0ull;
+                    break;
+                }
+                if ((uint32_t)__builtin_popcountll(sm) < keep) break;
+            }
+            if (sm != 0ull) { /* hand the running lanes over: (re, im) is the position after `done` iterations */
+                FR_COLD_PARAMS(kp);
+                const uint32_t sub_cap = kp->surv_sub_capacity;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(kp->surv_counts + list * FR_SURV_COUNT_STRIDE, (uint32_t)__builtin_popcountll(sm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+                if (running) {
+                    if (slot < sub_cap) {
+                        const size_t e = (size_t)list * sub_cap + slot;
+                        T2 zz;
+                        zz.x = re, zz.y = im;
+                        static_cast<T2 *>(kp->surv_z)[e] = zz;
+                        reinterpret_cast<uint2 *>(kp->surv_pos)[e] = make_uint2(cx, r_out);
+                        kp->surv_cnt[e] = done;
+                        if (!julia) {
+                            T2 cc2;
+                            cc2.x = cre, cc2.y = cim;
+                            static_cast<T2 *>(kp->surv_c)[e] = cc2;
+                        }
+                        handed_over = true;
+                    } else {
+                        slow = true, start = done; /* the list is full: finish here */
+                    }
+                }
+            }
+        }
+        /* the plain loop: a strip that may not use the scaled form (wave-uniform: start = 0 for all), or the
+         * lanes whose list was full (all of one tile: the same `start`) */
+        if (__ballot(slow) != 0ull && slow) {
+            const uint32_t rest = cap - start;
+            const uint32_t more = orbit<T>(rest, re, im, cre, cim, squared, r2, i2);
+            iters = more < rest ? start + more : cap;
+        }
+        if (valid && !handed_over) {
+            FR_COLD_PARAMS(kp);
+            const ColourConsts cc = make_colour_consts(*kp);
+            double dist;
+            if constexpr (sizeof(T) == 8) {
+                dist = (double)(r2 + i2); /* pos.squared_distance(), :214 */
+            } else {
+                const double zre = (double)re, zim = (double)im;
+                dist = zre * zre + zim * zim;
+            }
+            uint8_t rgb[3];
+            colour_of(cc, dist, iters, s_tab, s_pal, rgb);
+            store_pixel(kp->ncols, kp->out_rgba, out.rgb, r_out, cx, rgb);
+        }
+    }
+}
+
 /* ---- strip kernel with lane refill ------------------------------------------------------------
  *
  * One wave renders a patch of 7 x 2 tiles (56 x 16 pixels), and a lane whose pixel has finished
@@ -1239,12 +1423,24 @@ __device__ __forceinline__ unsigned long long finish_run(uint32_t iterations, T 
     return srun;
 }
 
-template <typename T, int M>
+/* SRC = 0: the pixels come from 64x32 patches of the image, as described above.
+ * SRC = 1: they come from the survivor lists the first pass (escape_first_kernel) left in device memory: a
+ *          "patch" is a chunk of up to FR_SURV_CHUNK entries of one list, a pixel arrives with its position
+ *          after first_cap iterations and starts counting there.  npatch_x / npatches_arg are unused: the
+ *          number of chunks follows from the lists' counters, read once by every wave (one counter per lane). */
+template <typename T, int M, int SRC>
 __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, const fr_kout out, uint32_t npatch_x,
-                                                          uint32_t npatches) {
+                                                          uint32_t npatches_arg) {
     static_assert(M == 4 || M == 2, "the main loop is the scaled form in blocks of M");
+    static_assert(FR_SURV_QUEUES == 64, "one list counter per lane");
+    typedef typename Pair<T>::type T2;
     __shared__ T s_x[kQPatchW], s_y[kQPatchH];
     __shared__ uint32_t s_orow[kQPatchH];
+    /* SRC 1: the open chunk's entries (position, output position, c for Mandelbrot) */
+    __shared__ T2 s_cz[FR_SURV_CHUNK], s_cc[FR_SURV_CHUNK];
+    __shared__ uint2 s_cpos[FR_SURV_CHUNK];
+    __shared__ uint32_t s_ccnt[FR_SURV_CHUNK];
+    static_assert(FR_SURV_CHUNK == 64, "a chunk is loaded one entry per lane");
     /* the stack of unfinished results: position and c (unscaled), iterations done, output position */
     __shared__ T q_re[kQStack], q_im[kQStack], q_cre[kQStack], q_cim[kQStack];
     __shared__ uint32_t q_it[kQStack], q_px[kQStack], q_py[kQStack];
@@ -1253,10 +1449,6 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
      * per 64) — is RE-READ from the kernel-argument segment there (scalar loads through a pointer the
      * optimiser cannot see through), instead of being held in SGPRs across the hot loop as kernel arguments
      * normally are: those ~50 values overflow the scalar file and every use became a v_readlane spill reload. */
-    typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
-#define FR_COLD_PARAMS(NAME)                                                          \
-    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is argument 0 */ \
-    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay in this phase */
     const uint32_t lane = threadIdx.x;
     const uint32_t *s_pal = nullptr;
     if (p.palette != nullptr) {
@@ -1290,8 +1482,83 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     uint32_t have_patch = 0, exhausted = 0, next = 0, vw = 0, vh = 0, pcol0 = 0;
     uint32_t patch_ok = 0; /* every pixel of the open patch may use the scaled form (all but a sliver of patches) */
     uint32_t qcount = 0, upper = 0; /* results waiting; upper bound of the running lanes' iteration counts */
-    uint32_t pref = 0;              /* lane 0: the id of the next patch (requested one patch ahead) */
-    if (lane == 0) pref = atomicAdd(counter, 1u);
+    /* Work is claimed through FR_SURV_QUEUES counters, not one: a single address takes 88 million atomics a
+     * second on this device and 64 addresses on 64 lines 4 100 million (tools/ubench/buffer_atomic_oob.hip) — a
+     * quarter of a million claims on one counter would be the bound of the whole kernel.  SRC 0: shard q holds
+     * the patches q, q + 64, ...; SRC 1: list q's chunks.  A claim is answered after ~3 us and the wave waits
+     * for it (every way of keeping it in flight across the loop either makes the compiler wait at once — the
+     * join after `if (lane == 0)` copies the result — or hides the access from it), so claims are made rare
+     * instead: a wave takes a BATCH of units, sized by what is left in its shard (guided self-scheduling:
+     * 1/(2 x waves per shard) of it, at most 4 — waves differ in speed by a factor of two, and a slow wave with
+     * 16 chunks in hand was the tail — down to single units at the end).
+     * When its shard is used up a wave looks at all 64 counters at once and moves to the next shard with work. */
+    uint32_t list_len = 0, chunk_n = 0;
+    if constexpr (SRC == 1) {
+        const uint32_t raw = p.surv_counts[lane * FR_SURV_COUNT_STRIDE];
+        list_len = raw < p.surv_sub_capacity ? raw : p.surv_sub_capacity;
+    }
+    const uint32_t units_lane = SRC == 1 ? (list_len + FR_SURV_CHUNK - 1u) / FR_SURV_CHUNK
+                                         : (npatches_arg > lane ? (npatches_arg - lane + FR_SURV_QUEUES - 1u) / FR_SURV_QUEUES : 0u);
+    uint32_t cur_q = blockIdx.x & (FR_SURV_QUEUES - 1u);
+    uint32_t batch_next = 0, batch_end = 0; /* the units of shard cur_q this wave holds: [batch_next, batch_end) */
+    const uint32_t claim_div = 2u * (gridDim.x / FR_SURV_QUEUES + 1u);
+    /* the next unit: unit j of shard cur_q; false = no work is left anywhere */
+    auto take_unit = [&](uint32_t &j) -> bool {
+        for (;;) {
+            if (batch_next < batch_end) {
+                j = batch_next++;
+                return true;
+            }
+            const uint32_t units_q = __builtin_amdgcn_readlane(units_lane, cur_q);
+            /* what was left when this wave last looked (others have claimed since: an upper bound) */
+            const uint32_t left = units_q > batch_end ? units_q - batch_end : 0u;
+            uint32_t size = SRC == 1 ? left / claim_div : 1u; /* (a batch of 64x32 patches is too coarse at the end) */
+            size = size < 1u ? 1u : (size > 4u ? 4u : size);
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(counter + cur_q * FR_SURV_COUNT_STRIDE, size);
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < units_q) {
+                batch_next = got;
+                batch_end = got + size < units_q ? got + size : units_q;
+                continue;
+            }
+            /* this shard is used up: look at every shard's counter */
+            const uint32_t claimed = __hip_atomic_load(counter + lane * FR_SURV_COUNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long m = __ballot(claimed < units_lane);
+            if (m == 0ull) return false; /* claims only grow: every shard is used up for good */
+            const uint32_t r = (cur_q + 1u) & 63u;
+            const unsigned long long m2 = r ? (m >> r) | (m << (64u - r)) : m;
+            cur_q = (cur_q + 1u + (uint32_t)__builtin_ctzll(m2)) & 63u;
+            batch_next = batch_end = __builtin_amdgcn_readlane(claimed, cur_q);
+        }
+    };
+    /* SRC 1: the NEXT chunk, already on its way into registers (one entry per lane); nx_n == 0: there is none */
+    uint32_t nx_n = 0;
+    T2 pf_z, pf_c;
+    uint2 pf_pos = make_uint2(0u, 0u);
+    uint32_t pf_cnt = 0;      /* iterations the entry's pixel has done */
+    const uint32_t first_cap = p.first_cap;
+    uint32_t chunk_maxcnt = 0; /* the largest of them in the open chunk */
+    pf_z.x = pf_z.y = pf_c.x = pf_c.y = (T)0;
+    /* SRC 1: start loading the next chunk's entries into the prefetch registers; they are waited for one chunk
+     * later, when their latency has long passed.  (Every lane loads — lanes past the chunk's end its entry 0 —
+     * so that no branch joins behind the loads: a join would copy the registers and wait right here.) */
+    auto prefetch_chunk = [&]() {
+        uint32_t j;
+        nx_n = 0;
+        if (take_unit(j)) {
+            FR_COLD_PARAMS(kp);
+            const uint32_t len = __builtin_amdgcn_readlane(list_len, cur_q);
+            const size_t base = (size_t)cur_q * kp->surv_sub_capacity + (size_t)j * FR_SURV_CHUNK;
+            nx_n = len - j * FR_SURV_CHUNK < FR_SURV_CHUNK ? len - j * FR_SURV_CHUNK : FR_SURV_CHUNK;
+            const size_t e = base + (lane < nx_n ? lane : 0u);
+            pf_z = static_cast<const T2 *>(kp->surv_z)[e];
+            pf_pos = reinterpret_cast<const uint2 *>(kp->surv_pos)[e];
+            pf_cnt = kp->surv_cnt[e];
+            if (!julia) pf_c = static_cast<const T2 *>(kp->surv_c)[e];
+        }
+    };
+    if constexpr (SRC == 1) prefetch_chunk();
 
     /* the finishing pass over the top 64 (or, at the end, all remaining) stack entries */
     auto finish_and_colour = [&](uint32_t base, uint32_t count) {
@@ -1365,12 +1632,33 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
     for (;;) {
         /* ---- 1. open the next patch when the current one is used up */
         FR_PHASE_BEGIN();
-        if (!have_patch && !exhausted) {
-            const uint32_t id = __builtin_amdgcn_readfirstlane(pref);
-            if (id >= npatches) {
+        if constexpr (SRC == 1) {
+            if (!have_patch && !exhausted) {
+                if (nx_n == 0) {
+                    exhausted = 1;
+                } else {
+                    __syncthreads(); /* earlier reads of the chunk arrays are done */
+                    s_cz[lane] = pf_z;
+                    s_cpos[lane] = pf_pos;
+                    s_ccnt[lane] = pf_cnt;
+                    if (!julia) s_cc[lane] = pf_c;
+                    /* nearly every chunk's entries left the first pass after its first episode */
+                    chunk_maxcnt = __ballot(lane < nx_n && pf_cnt != first_cap) == 0ull ? first_cap
+                                                                                        : wave_max_u32(lane < nx_n ? pf_cnt : 0u);
+                    __syncthreads();
+                    chunk_n = nx_n;
+                    have_patch = 1;
+                    next = 0;
+                    tr_patches++;
+                    prefetch_chunk();
+                }
+            }
+        } else if (!have_patch && !exhausted) {
+            uint32_t unit;
+            if (!take_unit(unit)) {
                 exhausted = 1;
             } else {
-                if (lane == 0) pref = atomicAdd(counter, 1u); /* its answer is needed one patch from now */
+                const uint32_t id = cur_q + unit * FR_SURV_QUEUES;
                 FR_COLD_PARAMS(kp);
                 const auto &P = *kp;
                 /* the patch's coordinate map (calc/src/lib.rs:182-197), one column and one row per lane */
@@ -1412,28 +1700,58 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
             const uint32_t pix = next + rank;
-            const uint32_t col = pix & (kQPatchW - 1), row = pix >> 6;
             bool direct = false; /* this pixel cannot enter the main loop: straight to the finishing pass */
             T sx = 0, sy = 0, cre = 0, cim = 0;
-            if (!busy && col < vw && row < vh) { /* row < vh <= kQPatchH also bounds pix */
-                sx = s_x[col], sy = s_y[row];
-                cre = julia ? jre : sx, cim = julia ? jim : sy; /* calc/src/lib.rs:209-210 */
-                X = sx + sx, Y = sy + sy, A = X * X, B = Y * Y, c2re = cre + cre, c2im = cim + cim;
-                px = pcol0 + col;
-                py = s_orow[row];
-                cnt = 0.0f;
-                /* the scaled form must be provably exact for this pixel, and it must start under T */
-                if ((patch_ok || lane_is_scalable<T>(sx, sy, cre, cim)) && A + B <= t4 && cap >= (uint32_t)M)
-                    busy = true;
-                else
-                    direct = true;
+            uint32_t start_count = 0; /* iterations the pixel has done when it arrives */
+            if constexpr (SRC == 1) {
+                if (!busy && pix < chunk_n) {
+                    const T2 zz = s_cz[pix];
+                    const uint2 pos = s_cpos[pix];
+                    start_count = s_ccnt[pix];
+                    sx = zz.x, sy = zz.y;
+                    cre = jre, cim = jim;
+                    if (!julia) {
+                        const T2 cc2 = s_cc[pix];
+                        cre = cc2.x, cim = cc2.y;
+                    }
+                    X = sx + sx, Y = sy + sy, A = X * X, B = Y * Y, c2re = cre + cre, c2im = cim + cim;
+                    px = pos.x, py = pos.y;
+                    cnt = (float)start_count;
+                    /* (the scaled form is exact for this orbit: the first pass hands over only pixels of strips
+                     * it ran in the scaled form itself — admissible start and c, see strip_is_scalable) */
+                    if (A + B <= t4 && start_count + (uint32_t)M <= cap)
+                        busy = true;
+                    else
+                        direct = true;
+                }
+                next += (uint32_t)__builtin_popcountll(free_mask);
+                if (next >= chunk_n) have_patch = 0;
+                if (upper < chunk_maxcnt) upper = chunk_maxcnt;
+            } else {
+                const uint32_t col = pix & (kQPatchW - 1), row = pix >> 6;
+                if (!busy && col < vw && row < vh) { /* row < vh <= kQPatchH also bounds pix */
+                    sx = s_x[col], sy = s_y[row];
+                    cre = julia ? jre : sx, cim = julia ? jim : sy; /* calc/src/lib.rs:209-210 */
+                    X = sx + sx, Y = sy + sy, A = X * X, B = Y * Y, c2re = cre + cre, c2im = cim + cim;
+                    px = pcol0 + col;
+                    py = s_orow[row];
+                    cnt = 0.0f;
+                    /* the scaled form must be provably exact for this pixel, and it must start under T */
+                    if ((patch_ok || lane_is_scalable<T>(sx, sy, cre, cim)) && A + B <= t4 && cap >= (uint32_t)M)
+                        busy = true;
+                    else
+                        direct = true;
+                }
+                next += (uint32_t)__builtin_popcountll(free_mask);
+                if ((next >> 6) >= vh) have_patch = 0;
             }
-            next += (uint32_t)__builtin_popcountll(free_mask);
-            if ((next >> 6) >= vh) have_patch = 0;
-            push(direct, sx, sy, cre, cim, 0u);
+            push(direct, sx, sy, cre, cim, start_count);
             busy_mask = __ballot(busy);
         }
         FR_PHASE_END(ph_refill);
+        if constexpr (SRC == 1) { /* the chunk ran out before the free lanes did: open the next one right away */
+            if (!have_patch && !exhausted && busy_mask != ~0ull) continue;
+        }
         if (busy_mask == 0ull) {
             if (!have_patch && exhausted) break;
             continue;
@@ -1476,15 +1794,16 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
         t[5] = tr_iters, t[6] = (ph_open & 0xFFFFFFFFull) | (ph_refill << 32), t[7] = (ph_loop & 0xFFFFFFFFull) | (ph_retire << 32);
         t[8] = ph_finish;
     }
-#undef FR_COLD_PARAMS
 #undef FR_PHASE_BEGIN
 #undef FR_PHASE_END
 }
 
-template <typename T, int M>
+template <typename T, int M, int SRC>
 hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
-    const uint64_t npx = ((uint64_t)p.ncols + kQPatchW - 1) / kQPatchW;
-    const uint64_t npy = ((uint64_t)p.nrows + kQPatchH - 1) / kQPatchH;
+    /* SRC 1: the number of chunks is known to the device only; size the persistent grid by an upper bound */
+    const uint64_t npx = SRC == 1 ? ((uint64_t)p.surv_sub_capacity + FR_SURV_CHUNK - 1) / FR_SURV_CHUNK
+                                  : ((uint64_t)p.ncols + kQPatchW - 1) / kQPatchW;
+    const uint64_t npy = SRC == 1 ? FR_SURV_QUEUES : ((uint64_t)p.nrows + kQPatchH - 1) / kQPatchH;
     if (npx * npy == 0) return hipSuccess;
     if (npx * npy > 0xFFF00000ull) return hipErrorInvalidConfiguration; /* the counter overshoots by one per wave */
     const size_t dyn = p.palette ? sizeof(uint32_t) * p.palette_entries : 0;
@@ -1500,13 +1819,13 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
         cached_device = dev;
     }
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, escape_queue_kernel<T, M>, 64, dyn);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, escape_queue_kernel<T, M, SRC>, 64, dyn);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 32) per_cu = 32;
     uint64_t grid = (uint64_t)per_cu * (uint64_t)cached_cus;
     if (grid > npx * npy) grid = npx * npy;
-    hipLaunchKernelGGL((escape_queue_kernel<T, M>), dim3((uint32_t)grid), dim3(64), dyn, stream, p, out, (uint32_t)npx,
+    hipLaunchKernelGGL((escape_queue_kernel<T, M, SRC>), dim3((uint32_t)grid), dim3(64), dyn, stream, p, out, (uint32_t)npx,
                        (uint32_t)(npx * npy));
     return hipGetLastError();
 }
@@ -1514,8 +1833,30 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
 /* RGB output only; needs p.work_counter (zeroed on the launch stream by the caller) */
 template <typename T>
 hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
-    if (p.loop_mode == 4) return launch_queue_form<T, 4>(p, out, stream);
-    return launch_queue_form<T, 2>(p, out, stream);
+    if (p.loop_mode == 4) return launch_queue_form<T, 4, 0>(p, out, stream);
+    return launch_queue_form<T, 2, 0>(p, out, stream);
+}
+
+/* Two passes, RGB output only; needs the survivor lists and p.work_counter (all counters zeroed on the launch
+ * stream by the caller) and 0 < p.first_cap < p.iterations */
+template <typename T>
+hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
+    if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
+    constexpr int kStripTiles = 7;
+    const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
+    const uint64_t row_tiles = ((uint64_t)p.nrows + 7) / 8;
+    const uint64_t gy = row_tiles < 32768 ? row_tiles : 32768;
+    const uint64_t gz = (row_tiles + gy - 1) / gy;
+    if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
+    const dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
+    if (p.loop_mode == 4)
+        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles>), grid, dim3(64), 0, stream, p, out);
+    else
+        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles>), grid, dim3(64), 0, stream, p, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (p.loop_mode == 4) return launch_queue_form<T, 4, 1>(p, out, stream);
+    return launch_queue_form<T, 2, 1>(p, out, stream);
 }
 
 template <typename T, int kStripTiles>
@@ -1569,7 +1910,7 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 template <typename T>
 hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream,
                             const char *&name) {
-    if (p.out_in_place && tile > 10) tile = 0; /* only the strip kernels know in-place addressing */
+    if (p.out_in_place && tile > 11) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
         name = FR_KNAME("escape_kernel", "64x1");
@@ -1591,9 +1932,10 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
-            if (p.algo == 2 && mode == FR_OUT_RGB && p.work_counter && fr_wants_work_queue(p, 0)) {
-                name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x32-px patches");
-                return launch_queue<T>(p, out, stream);
+            if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
+                /* Julia views are mostly short orbits with a heavy tail: two passes (see escape_first_kernel) */
+                name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+                return launch_two_pass<T>(p, out, stream);
             }
             if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) {
                 name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
@@ -1616,6 +1958,17 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
     case 8:
         name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
+    case 11: /* two passes: strips to first_cap, then the work-queue kernel over the survivors (otherwise as 9) */
+        if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
+            name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            return launch_two_pass<T>(p, out, stream);
+        }
+        if (p.algo != 0 && p.algo != 2) {
+            name = FR_KNAME("escape_strip_kernel", "7 tiles");
+            return launch_strips<T, 7>(p, mode, out, stream);
+        }
+        name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
+        return launch_refill<T, 7>(p, mode, out, stream);
     case 10: /* the work-queue kernel (RGB output of an escape-time algorithm; otherwise as 9) */
         if (mode == FR_OUT_RGB && p.work_counter && fr_wants_work_queue(p, 10)) {
             name = FR_KNAME("escape_queue_kernel", "persistent waves, 64x32-px patches");
@@ -1739,6 +2092,41 @@ bool fr_wants_work_queue(const fr_kparams &p, int tile) {
     /* only on request: on BASELINE C4 it runs 3.5 ms (f32) / 5.0 ms (f64) against the patch-refill kernel's
      * 3.1 / 4.6, so the default dispatch for large Julia images stays with patch refill */
     return tile == 10;
+}
+
+bool fr_wants_two_pass(fr_kparams &p, int precision, int tile) {
+    (void)precision;
+    p.first_cap = 0;
+    if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
+    if (p.loop_mode == 0 || p.iterations >= (1u << 24)) return false; /* as for the work-queue kernel */
+    if (p.ncols == 0 || p.nrows == 0 || (uint64_t)p.ncols * p.nrows > 0xFFF00000ull) return false;
+    if (tile == 0) { /* the default dispatch: large Julia images (what launch_precision's case 0 tests) */
+        const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
+        if (p.algo != 2 || tiles < 262144) return false;
+    } else if (tile != 11) {
+        return false;
+    }
+    /* first_cap: a multiple of the loop's block length; the second pass must have something left to do */
+    uint32_t k1 = p.two_pass_cap ? p.two_pass_cap : 64u; /* measured on C4: 64 / 48 (tools/sweep_two_pass.py) */
+    k1 = (k1 + 3u) & ~3u;
+    if (k1 + 8u > p.iterations) return false;
+    p.first_cap = k1;
+    if (p.first_keep == 0 || p.first_keep > 64) p.first_keep = 48;
+    return true;
+}
+
+fr_two_pass_layout fr_two_pass_bytes(const fr_kparams &p, int precision, uint32_t sub_capacity) {
+    const size_t entries = (size_t)sub_capacity * FR_SURV_QUEUES;
+    const size_t pair = precision == 1 ? 8 : 16;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    fr_two_pass_layout l{};
+    l.z_off = 0;
+    l.pos_off = up(entries * pair);
+    l.cnt_off = l.pos_off + up(entries * 8);
+    l.c_off = l.cnt_off + up(entries * 4);
+    l.counts_off = l.c_off + (p.algo == 2 ? 0 : up(entries * pair));
+    l.total = l.counts_off + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE * sizeof(uint32_t);
+    return l;
 }
 
 hipError_t fr_launch_nu_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hipStream_t stream) {

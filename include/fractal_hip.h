@@ -297,18 +297,26 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
  * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
  * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
- * 9 = 7-tile strips with lane refill (the default for large Julia images);
+ * 9 = 7-tile strips with lane refill;
  * 10 = the work-queue kernel (persistent waves drawing 64x32-pixel patches from a device-wide counter, unchecked
  *      blocks of iterations, results finished and coloured 64 at a time; RGB renders of an escape-time algorithm
  *      whose loop plan allows the scaled form — otherwise it acts as 9);
+ * 11 = two passes (the default for large Julia images): 7-tile strips run every pixel through episodes of a few
+ *      dozen iterations and colour what has escaped, tile by tile; a tile whose running lanes fall under a
+ *      threshold hands them — position, iterations done, output position — to lists in device memory, which the
+ *      work-queue kernel's persistent waves then finish.  Same conditions as 10 (otherwise it acts as 9).  The
+ *      lists live in a context-owned scratch buffer of 20-36 bytes per entry, one entry per four pixels of the
+ *      launch (at most 2^28 entries); a list that is full costs speed only;
  * 6401, 3202, 1604, 808 = the 4-wave-workgroup kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave
  * pixel footprint. */
 int fr_set_tile(int tile);
 
 /* Policy of the lane-refilling kernels (tuning studies): an orbit episode may end early, so that
  * idle lanes get new pixels, once quit16/16 of its running lanes (work-queue kernel: of the wave's 64 lanes)
- * have finished and at least `minrun` iterations were done.  -1 = the kernel's own measured default.  Does not
- * affect results. */
+ * have finished and at least `minrun` iterations were done.  With tile 11 the two numbers steer its first pass
+ * instead: `minrun` = the length of an episode (default 64), `quit16` x 4 = the running lanes a tile needs to stay
+ * in the first pass for another episode (default 12: 48 lanes).  -1 = the kernel's own measured default.  Does
+ * not affect results. */
 int fr_set_refill_policy(int minrun, int quit16);
 
 /* Exact periodicity shortcut, OFF by default.  When on, large images are rendered by the refilling
@@ -348,6 +356,9 @@ int fr_debug_math(int which, const double *in, double *out, size_t n);
 /* Tuning aid: a device buffer of 16 uint64 per persistent wave (8192 waves is enough) to which the work-queue
  * kernel's waves write their start / end times (100 MHz ticks) and work counts; NULL turns it off. */
 int fr_debug_set_queue_trace(void *d_trace);
+/* Test aid: entries per survivor list of the two-pass render (tile 11); 0 = sized from the image.  A tiny
+ * value makes the lists overflow, which the first pass absorbs by finishing those pixels itself. */
+int fr_debug_set_two_pass_capacity(uint32_t entries_per_list);
 
 #ifdef __cplusplus
 }

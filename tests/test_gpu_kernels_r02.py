@@ -70,7 +70,7 @@ def test_contraction_sensitive_kats_on_every_loop_form(fr, lib, fmt, kats):
         assert O.lib().fro_xy_to_imaginary(C.byref(ocfg), 0, 0).im == im
         cfg = to_fr(fr, ocfg)
         for mode in (0, 2, 4):
-            for tile in (0, 9, 10, 808):
+            for tile in (0, 9, 10, 11, 808):
                 try:
                     _native.check(lib.fr_set_loop_mode(mode))
                     _native.check(lib.fr_set_tile(tile))
@@ -193,14 +193,41 @@ def test_work_queue_kernel_matches_the_oracle(fr, case):
             assert np.array_equal(got, want), (case, prec, minrun, quit16)
 
 
-def test_work_queue_kernel_row_bands_rgba_and_in_place_blocks(fr, lib):
+@pytest.mark.parametrize("case", QUEUE_CASES)
+def test_two_pass_render_matches_the_oracle(fr, lib, case):
+    """tile 11: strips to the end of their first episodes, the rest through the survivor lists (fr_kernels.hip,
+    escape_first_kernel): every episode length / keep threshold, lists that overflow, loop plans that rule it out."""
+    kw = dict(case)
+    w, h, algo = kw.pop("width"), kw.pop("height"), kw.pop("algo", O.MANDELBROT)
+    ocfg = O.cli_config(w, h, algo, **kw)
+    cfg = to_fr(fr, ocfg)
+    for prec, oprec in ((fr.Precision.F64, O.F64), (fr.Precision.F32, O.F32)):
+        want = O.get_image(ocfg, oprec)
+        for loop_mode in (-1, 0, 2):
+            got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, loop_mode=loop_mode))
+            assert np.array_equal(got, want), (case, prec, loop_mode)
+        # minrun = episode length, quit16 = lanes / 4 a tile must keep running to stay in the first pass
+        for episode, keep16 in ((4, 1), (8, 16), (64, 12), (200, 8), (1000, 4)):
+            got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, refill_minrun=episode, refill_quit16=keep16))
+            assert np.array_equal(got, want), (case, prec, episode, keep16)
+        try:  # lists of 64 entries each: nearly everything overflows and is finished by the first pass itself
+            lib.fr_debug_set_two_pass_capacity(64)
+            for episode in (-1, 8):
+                got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, refill_minrun=episode))
+                assert np.array_equal(got, want), (case, prec, "overflow", episode)
+        finally:
+            lib.fr_debug_set_two_pass_capacity(0)
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+def test_work_queue_kernel_row_bands_rgba_and_in_place_blocks(fr, lib, tile):
     import torch
     from fractal_renderer_amd import _native
 
     ocfg = O.cli_config(777, 613, O.JULIA, julia_set=(-0.8, 0.156), iterations=350)
     cfg = to_fr(fr, ocfg)
     want = O.get_image(ocfg)
-    o = fr.RenderOpts(tile=10)
+    o = fr.RenderOpts(tile=tile)
     # row bands rendered on their own
     for y0, y1 in ((0, 613), (100, 117), (600, 613), (5, 6)):
         assert np.array_equal(fr.get_image_rows(cfg, y0, y1, 0, opts=o), want[y0:y1])
@@ -262,12 +289,14 @@ def test_full_size_c4_work_queue_kernel(fr, lib, prec_name):
     view = img.view(16384, 16384, 3)
     assert np.array_equal(view[::16, ::16].cpu().numpy(), want)
     assert torch.equal(view[1:, 1:], torch.flip(view[1:, 1:], dims=(0, 1)))
-    other, name9 = render()
-    assert name9.startswith(b"escape_refill_kernel"), name9
-    assert torch.equal(img, other)
-    del other
-    exact, _ = render(tile=10, colour_filter=0)
-    assert torch.equal(img, exact)
+    # the default dispatch for an image like this: two passes; the patch-refill kernel; both with the filter off
+    for kw, kernel in ((dict(), b"escape_first_kernel + escape_queue_kernel"), (dict(tile=9), b"escape_refill_kernel"),
+                       (dict(tile=11, refill_minrun=128, refill_quit16=16), b"escape_first_kernel + escape_queue_kernel"),
+                       (dict(colour_filter=0), b"escape_first_kernel"), (dict(tile=10, colour_filter=0), b"escape_queue_kernel")):
+        other, name_o = render(**kw)
+        assert name_o.startswith(kernel), (kw, name_o)
+        assert torch.equal(img, other), kw
+        del other
 
 
 @pytest.mark.parametrize("view", ["c2", "c3"])
@@ -286,7 +315,7 @@ def test_full_size_mandelbrot_work_queue_kernel_equals_default(fr, lib, view):
     need = 3 * 16384 * 16384
     s = torch.cuda.current_stream()
     imgs = []
-    for tile in (0, 10):
+    for tile in (0, 10, 11):
         d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
         o = fr.RenderOpts(tile=tile)
         _native.check(lib.fr_set_profiling(1))
@@ -295,10 +324,10 @@ def test_full_size_mandelbrot_work_queue_kernel_equals_default(fr, lib, view):
         name = C.create_string_buffer(160)
         _native.check(lib.fr_last_kernel_name(name, len(name)))
         _native.check(lib.fr_set_profiling(0))
-        assert name.value.startswith(b"escape_queue_kernel" if tile == 10 else b"escape_strip_kernel"), name.value
+        assert name.value.startswith({0: b"escape_strip_kernel", 10: b"escape_queue_kernel", 11: b"escape_first_kernel"}[tile]), name.value
         imgs.append(d)
     torch.cuda.synchronize()
-    assert torch.equal(imgs[0], imgs[1])
+    assert torch.equal(imgs[0], imgs[1]) and torch.equal(imgs[0], imgs[2])
 
 
 # ---- the scaled loop at the edges of its admissible range ---------------------------------------------

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-wave trace of the work-queue kernel on BASELINE C4: how long each persistent wave lived, how many
-patches / episodes / colour passes / iterations it ran.  Usage: python tools/queue_trace.py [f32|f64] [extra bench-like env]"""
+patches / episodes / colour passes / iterations it ran.  Usage: python tools/queue_trace.py [f32|f64] [tile: 10 = over the image, 11 = second pass of the two-pass render] [first_cap]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +15,10 @@ from fractal_renderer_amd import _native  # noqa: E402
 prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else 0
 lib = _native.load()
 fr.init(0)
-_native.check(lib.fr_set_tile(10))  # the work-queue kernel (the default dispatch for this image is patch refill)
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+_native.check(lib.fr_set_tile(tile))  # 10: the work-queue kernel over the image; 11: over the first pass's survivor lists
+if len(sys.argv) > 3:
+    _native.check(lib.fr_set_refill_policy(int(sys.argv[3]), -1))
 cfg = fr.Config.new(fr.Algo.Julia)
 cfg.width = cfg.height = 16384
 cfg.iterations = 4096

@@ -74,6 +74,27 @@ DEF_KERNEL(k_mix_orbit, OP3("v_mul_f64", 0), OP3("v_add_f64", 1), OP3("v_add_f64
 DEF_KERNEL(k_mix_f64_u32, OP3("v_mul_f64", 0), MAXU(1), OP3("v_add_f64", 2), MAXU(3), OP3("v_mul_f64", 4), MAXU(5),
            OP3("v_add_f64", 6), MAXU(7))
 
+// scalar ALU: does a wave's SALU work hide behind the other waves' VALU work, and at what rate does a SIMD
+// take scalar instructions at all?  (Bodies of 32 instructions like the others.)
+#define SALU_KERNEL(NAME, BODY)                                                                   \
+    __global__ void NAME(unsigned long long *out, int iters, double seed) {                      \
+        float a0 = (float)seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, k = 1.0000001f;           \
+        for (int i = 0; i < iters; i++) {                                                        \
+            asm volatile(BODY BODY BODY BODY                                                      \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                 \
+                         : "v"(k)                                                                 \
+                         : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "scc");        \
+        }                                                                                        \
+        if (a0 + a1 + a2 + a3 == 12345.678f) out[0] = 0;                                          \
+    }
+#define S4 "s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n s_add_u32 s42, s42, 1\n s_add_u32 s43, s43, 1\n"
+#define V4 "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n"
+SALU_KERNEL(k_salu, S4 S4)                   // 8 scalar
+SALU_KERNEL(k_valu32, V4 V4)                 // 8 f32 vector
+SALU_KERNEL(k_v4s4, V4 S4)                   // 4 vector + 4 scalar
+SALU_KERNEL(k_v6s2, V4 "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n s_add_u32 s40, s40, 1\n s_add_u32 s41, s41, 1\n")
+SALU_KERNEL(k_v7s1, V4 "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n s_add_u32 s40, s40, 1\n")
+
 typedef void (*kern_t)(unsigned long long *, int, double);
 
 int main() {
@@ -87,6 +108,8 @@ int main() {
         {"v_mov_b32", k_mov_b32}, {"v_mov_b64", k_mov_b64}, {"v_mul_f32", k_mul_f32},
         {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32},
         {"mix 3mul+4add+cmp f64", k_mix_orbit}, {"mix f64/u32 alternating", k_mix_f64_u32},
+        {"s_add_u32", k_salu}, {"v_mul_f32 (4 chains)", k_valu32}, {"4 v_mul_f32 + 4 s_add_u32", k_v4s4},
+        {"6 v_mul_f32 + 2 s_add_u32", k_v6s2}, {"7 v_mul_f32 + 1 s_add_u32", k_v7s1},
     };
     unsigned long long *d;
     hipMalloc(&d, sizeof(unsigned long long) * 256 * 4 * 8 * 4);
