@@ -887,6 +887,11 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     uint32_t row0, tile0, ncols, nrows, r_out;
     double coord_lane, sim;
     bool strip_scalable;
+    /* where the strip's pixels go: a wave-uniform base and one 32-bit byte offset per lane, computed once — the
+     * general form, (row * ncols + col) * 3 in 64 bits per pixel, is three quarter-rate v_mad_u64_u32 per tile */
+    uint8_t *strip_base;
+    uint32_t off_lane, bpp;
+    bool narrow; /* the 8 rows of a strip span less than 4 GiB: always, short of a 178-million-pixel-wide image */
     {
         FR_COLD_PARAMS(kp);
         const auto &P = *kp;
@@ -924,6 +929,10 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         uint32_t out_row0 = row0;
         if (P.out_in_place) out_row0 = y_first + (row0 / block_rows) * y_stride + row0 % block_rows;
         r_out = out_row0 + ly;
+        bpp = P.out_rgba ? 4u : 3u;
+        narrow = (uint64_t)ncols * bpp * 8u <= 0xFFFFFFFFull;
+        off_lane = ly * (ncols * bpp) + (lane & 7u) * bpp;
+        strip_base = out.rgb + ((uint64_t)out_row0 * ncols + (uint64_t)tile0 * 8u) * bpp;
         const bool relevant = lane >= 56 ? (row0 + (lane - 56) < nrows) : (tile0 * 8u + lane < ncols);
         strip_scalable = coords_admissible<T>(P.algo == 2, P.julia_re, P.julia_im, coord_lane, relevant);
     }
@@ -1019,7 +1028,18 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
             }
             uint8_t rgb[3];
             colour_of(cc, dist, iters, s_tab, s_pal, rgb);
-            store_pixel(kp->ncols, kp->out_rgba, out.rgb, r_out, cx, rgb);
+            if (narrow) {
+                uint8_t *o = strip_base + (size_t)((uint32_t)k * 8u * bpp) + (size_t)off_lane;
+                if (bpp == 4u) {
+                    *reinterpret_cast<uint32_t *>(o) = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16) | 0xFF000000u;
+                } else {
+                    o[0] = rgb[0];
+                    o[1] = rgb[1];
+                    o[2] = rgb[2];
+                }
+            } else {
+                store_pixel(kp->ncols, kp->out_rgba, out.rgb, r_out, cx, rgb);
+            }
         }
     }
 }
