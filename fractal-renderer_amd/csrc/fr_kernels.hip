@@ -1948,15 +1948,16 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         /* strip length by image size: long strips amortise the per-workgroup setup, short ones
          * keep every SIMD supplied with several waves when the image is small (GUI frames) */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
+        if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
+            /* Julia views are mostly short orbits with a heavy tail: two passes (see escape_first_kernel; the
+             * host asks for it from 65 536 tiles up: fr_wants_two_pass) */
+            name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            return launch_two_pass<T>(p, out, stream);
+        }
         if (tiles >= 262144) {
             /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
              * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
              * default view and a 10^6 zoom) and skip the bookkeeping. */
-            if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
-                /* Julia views are mostly short orbits with a heavy tail: two passes (see escape_first_kernel) */
-                name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
-                return launch_two_pass<T>(p, out, stream);
-            }
             if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) {
                 name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
                 return launch_refill<T, 7>(p, mode, out, stream);
@@ -2120,9 +2121,12 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile) {
     if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
     if (p.loop_mode == 0 || p.iterations >= (1u << 24)) return false; /* as for the work-queue kernel */
     if (p.ncols == 0 || p.nrows == 0 || (uint64_t)p.ncols * p.nrows > 0xFFF00000ull) return false;
-    if (tile == 0) { /* the default dispatch: large Julia images (what launch_precision's case 0 tests) */
+    if (tile == 0) {
+        /* the default dispatch: Julia images from 2048^2 up.  Measured (tools/two_pass_sizes.py, C4's view, f32 /
+         * f64, against the strips the default would otherwise pick): 65 536 tiles 0.17 / 0.21 ms against 0.18 / 0.30,
+         * 131 072 tiles 0.17 / 0.22 against 0.20 / 0.33; at 32 768 tiles and below the strips win in f32 */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
-        if (p.algo != 2 || tiles < 262144) return false;
+        if (p.algo != 2 || tiles < 65536) return false;
     } else if (tile != 11) {
         return false;
     }

@@ -301,7 +301,7 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
  * 10 = the work-queue kernel (persistent waves drawing 64x32-pixel patches from a device-wide counter, unchecked
  *      blocks of iterations, results finished and coloured 64 at a time; RGB renders of an escape-time algorithm
  *      whose loop plan allows the scaled form — otherwise it acts as 9);
- * 11 = two passes (the default for large Julia images): 7-tile strips run every pixel through episodes of a few
+ * 11 = two passes (the default for Julia images of 2048^2 pixels and more): 7-tile strips run every pixel through episodes of a few
  *      dozen iterations and colour what has escaped, tile by tile; a tile whose running lanes fall under a
  *      threshold hands them — position, iterations done, output position — to lists in device memory, which the
  *      work-queue kernel's persistent waves then finish.  Same conditions as 10 (otherwise it acts as 9).  The
