@@ -372,7 +372,10 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     for (int k = 0; k < 3; k++) {
         p.filt_d[k] = p.prim_f[k] * ak * FR_NU_BRACKET * (1.0 + 0x1p-20);
         p.filt_d32[k] = p.colour_filter32 ? std::nextafterf((float)(p.prim_f[k] * ak * FR_NU_BRACKET * (1.0 + 0x1p-10)), INFINITY) : 0.0f;
+        p.prim32[k] = (float)p.prim[k];
     }
+    const double lo = std::fmax(cfg->stable_limit, 2.0) * (1.0 + 0x1p-20);
+    p.filt_lo32 = (p.colour_filter32 && lo < 1e30) ? std::nextafterf((float)lo, INFINITY) : INFINITY;
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 — evaluated on the host ONLY to bound |c| over a launch
@@ -1113,6 +1116,15 @@ int fr_debug_math(int which, const double *in, double *out, size_t n) {
         HIP_TRY(fr_launch_nu_scan((uint32_t)in[0], (uint32_t)in[1], d_out, ctx->stream));
         HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return FR_OK;
+    }
+    if (which == 6) { /* packed-cast scan: in[0], in[1] = first and last f32 bit pattern; out[0] = mismatches */
+        if (n < 2) return fail(FR_ERR_INVALID_ARGUMENT, "which == 6 needs n >= 2");
+        HIP_TRY(fr_launch_cast_scan((uint32_t)in[0], (uint32_t)in[1], d_out, ctx->stream));
+        unsigned long long bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, d_out, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        out[0] = (double)bad;
         return FR_OK;
     }
     HIP_TRY(hipMemcpyAsync(d_in, in, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

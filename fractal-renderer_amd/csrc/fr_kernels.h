@@ -69,6 +69,10 @@ struct fr_kparams {
     uint32_t colour_filter32;
     float filt_k32;    /* (float)filt_k */
     float filt_d32[3]; /* the same half-widths, times (1 + 2^-10), rounded up to f32 */
+    float prim32[3];   /* the stored colour fields as f32 (exact) */
+    /* f32 renders: max(stable_limit, 2) * (1 + 2^-20) rounded up — an f32 squared distance at or above it proves
+     * dist > stable_limit and dist >= 2 (fr_kernels.hip: colour_pixel); +inf = never take that shortcut */
+    float filt_lo32;
     /* two-pass rendering (fr_kernels.hip, "first pass + survivor list"): the first pass runs every pixel
      * `first_cap` iterations and appends the orbits still going to one of FR_SURV_QUEUES lists in device
      * memory; the second pass (the work-queue kernel, drawing from those lists) finishes them.
@@ -152,5 +156,9 @@ hipError_t fr_launch_math_probe(int which, const double *in, double *out, size_t
 
 /* test hook: largest |filter bracket centre - f64 nu| over every f32 bit pattern in [lo, hi] -> out[0] (device) */
 hipError_t fr_launch_nu_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hipStream_t stream);
+
+/* test hook: the number of f32 bit patterns in [lo, hi] on which the packed `as u8` cast differs from the plain
+ * one -> the 8 bytes at out (device) as a uint64 */
+hipError_t fr_launch_cast_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hipStream_t stream);
 
 #endif

@@ -48,6 +48,7 @@ struct ColourConsts {
     double filt_d[3];       /* prim[k] * |filt_k| * FR_NU_BRACKET * (1 + 2^-20): the bracket's half-width in byte units */
     uint32_t filter32;      /* ... and before that, the same test carried out in f32 */
     float filt_k32, filt_d32[3], prim32[3];
+    float filt_lo32;        /* f32 renders: an f32 squared distance at or above this is surely > stable_limit and >= 2 */
 };
 
 template <typename P>
@@ -70,8 +71,9 @@ __device__ __forceinline__ ColourConsts make_colour_consts(const P &p) {
     c.filt_k32 = p.filt_k32;
     for (int k = 0; k < 3; k++) {
         c.filt_d32[k] = p.filt_d32[k];
-        c.prim32[k] = (float)p.prim[k];
+        c.prim32[k] = p.prim32[k];
     }
+    c.filt_lo32 = p.filt_lo32;
     return c;
 }
 
@@ -90,6 +92,21 @@ __device__ __forceinline__ uint32_t sat_u8_dev(float v) { /* the same, from an f
     uint32_t u;
     asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(v));
     return u < 255u ? u : 255u;
+}
+
+/* The same cast, from an f32, written straight into byte `k` of a packed word: v_floor_f32 + v_cvt_pk_u8_f32.
+ * The pack instruction rounds to nearest even and saturates (NaN -> 0); behind a floor that is truncation for
+ * every value that does not saturate to 0 anyway.  Equal to sat_u8_dev(float) on EVERY f32 bit pattern
+ * (tools/ubench/cvt_pk_u8.hip scans them all; test_device_packed_saturating_cast does the same through the
+ * library).  Two half-cost instructions instead of a convert and a full-cost integer min, and the three bytes
+ * of a pixel arrive packed. */
+template <int K>
+__device__ __forceinline__ uint32_t sat_u8_pack(float v, uint32_t acc) {
+    float f;
+    uint32_t u;
+    asm("v_floor_f32 %0, %1" : "=v"(f) : "v"(v));
+    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(u) : "v"(f), "n"(K), "v"(acc));
+    return u;
 }
 
 __device__ __forceinline__ void colour_multiply(const double col[3], double mult, uint8_t out[3]) {
@@ -125,29 +142,40 @@ __device__ __forceinline__ void colour_outside_flat(const ColourConsts &c, uint3
  * [2, 2^120] on the device and asserts the composite error of a stays under 1.5e-6.
  * Pixels outside that range of dist, and pixels whose widened value touches a cell boundary (about one in
  * 10^5), take the exact path.  Same bytes either way; fr_set_colour_filter(0) forces the exact path. */
+/* Stage 1, all in f32 (instructions at half the f64 cost), from an f32 squared distance d32:
+ * v32 = col * ((iters + 1 - nu32) * K32).  Four f32 roundings and K's own put it within |v| * 2.4e-7 of
+ * col * (iters + 1 - nu32) * K, which is within col * |K| * E of the real value (nu is within E of nu32); the
+ * window used is |v32| * 2^-21 + filt_d32 (the host rounds that term up), twice the relative part, so that the
+ * roundings of the window's own ends are covered too.  (iterations < 2^24 and 2^-60 <= |K| <= 2^60 — the host
+ * checks — keep every step exact enough: iters + 1 converts exactly, nothing under- or overflows.)  Both ends of
+ * the window are cast into packed bytes, so one comparison decides all three channels.  Returns, per lane,
+ * whether the byte triple is decided (and then out[] holds it). */
+__device__ __forceinline__ bool colour_filter_stage1(const ColourConsts &c, float d32, bool in_range, uint32_t iters_u,
+                                                     float &nu32, uint8_t out[3]) {
+    const float l1 = __builtin_amdgcn_logf(d32);
+    nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
+    const int ch[3] = {0, 2, 1}; /* color_multiply's RGB::new(r, b, g) swap, as in colour_multiply() */
+    const float m32 = ((float)(iters_u + 1u) - nu32) * c.filt_k32;
+    const float v0 = c.prim32[ch[0]] * m32, v1 = c.prim32[ch[1]] * m32, v2 = c.prim32[ch[2]] * m32;
+    const float w0 = __builtin_fmaf(__builtin_fabsf(v0), 0x1p-21f, c.filt_d32[ch[0]]);
+    const float w1 = __builtin_fmaf(__builtin_fabsf(v1), 0x1p-21f, c.filt_d32[ch[1]]);
+    const float w2 = __builtin_fmaf(__builtin_fabsf(v2), 0x1p-21f, c.filt_d32[ch[2]]);
+    const uint32_t lo = sat_u8_pack<2>(v2 - w2, sat_u8_pack<1>(v1 - w1, sat_u8_pack<0>(v0 - w0, 0u)));
+    const uint32_t hi = sat_u8_pack<2>(v2 + w2, sat_u8_pack<1>(v1 + w1, sat_u8_pack<0>(v0 + w0, 0u)));
+    out[0] = (uint8_t)lo, out[1] = (uint8_t)(lo >> 8), out[2] = (uint8_t)(lo >> 16);
+    return in_range && lo == hi;
+}
+
 __device__ __forceinline__ bool colour_outside_filtered(const ColourConsts &c, double dist, uint32_t iters_u, uint8_t out[3]) {
     const bool in_range = dist >= 2.0 && dist <= 0x1p120;
-    const float l1 = __builtin_amdgcn_logf((float)dist);
-    const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
-    const int ch[3] = {0, 2, 1}; /* color_multiply's RGB::new(r, b, g) swap, as in colour_multiply() */
-    /* Stage 1, all in f32 (instructions at half the f64 cost): v32 = col * ((iters + 1 - nu32) * K32).  Four f32
-     * roundings and K's own put it within |v| * 2.4e-7 of col * (iters + 1 - nu32) * K, which is within
-     * col * |K| * E of the real value (nu is within E of nu32); the window used is |v32| * 2^-21 + filt_d32 (the
-     * host rounds that term up), twice the relative part, so that the roundings of the window's own ends are
-     * covered too.  (iterations < 2^24 and 2^-60 <= |K| <= 2^60 — the host checks — keep every step exact
-     * enough: iters + 1 converts exactly, nothing under- or overflows.)  A wave whose lanes all pass is done;
-     * about one wave in fifty is not and goes on to stage 2. */
+    const int ch[3] = {0, 2, 1};
+    float nu32;
+    /* A wave whose lanes all pass stage 1 is done; about one wave in fifty is not and goes on to stage 2. */
     if (c.filter32) {
-        const float m32 = ((float)(iters_u + 1u) - nu32) * c.filt_k32;
-        bool same32 = in_range;
-        for (int k = 0; k < 3; k++) {
-            const float v = c.prim32[ch[k]] * m32;
-            const float w = __builtin_fmaf(__builtin_fabsf(v), 0x1p-21f, c.filt_d32[ch[k]]);
-            const uint32_t lo = sat_u8_dev(v - w), hi = sat_u8_dev(v + w);
-            same32 = same32 && lo == hi;
-            out[k] = (uint8_t)lo;
-        }
+        const bool same32 = colour_filter_stage1(c, (float)dist, in_range, iters_u, nu32, out);
         if (__ballot(!same32) == 0ull) return true;
+    } else {
+        nu32 = __builtin_amdgcn_logf(__builtin_amdgcn_logf((float)dist) * 0.25f);
     }
     /* Stage 2: the same test with the arithmetic after nu32 in f64 (window: |v| * 2^-46 + filt_d) */
     const double it2 = ((double)iters_u + 1.0) - (double)nu32; /* iters + 1 is exact */
@@ -192,6 +220,41 @@ __device__ __forceinline__ void colour_of(const ColourConsts &c, double dist, ui
     } else {
         out[0] = out[1] = out[2] = 0; /* :233 */
     }
+}
+
+/* The colour of the pixel recursive() left at (re, im) (r2 = re*re, i2 = im*im) after `iters_u`.
+ *
+ * f64 renders: dist = r2 + i2, the reference's squared_distance() (:214).  f32 renders: the reference's arithmetic
+ * on the f32 position is zre*zre + zim*zim in f64 — two conversions, two multiplies, an add, and then three f64
+ * compares and a conversion back before the filter's f32 stage can start: a third of the colour map's cost.  So
+ * the f32 kernels first try with d32 = fl32(re*re + im*im), which is within 2^-23 (relative) of that f64 value:
+ *   - d32 >= filt_lo32 (the host's max(stable_limit, 2) * (1 + 2^-20), rounded up) and d32 <= 2^120 (1 - 2^-20)
+ *     PROVE dist > stable_limit and 2 <= dist <= 2^120, the branch and the range the filter needs;
+ *   - as the logarithm's argument d32 moves nu by at most 2^-23 / (ln 2)^2 = 2.5e-7 on top of the 1.5e-6 the
+ *     scan over every f32 allows (test_colour_filter_bracket_holds_for_every_f32): 1.75e-6, inside the bracket
+ *     E = 2^-18 = 3.8e-6 the windows are built from.
+ * A wave in which every lane passes both, and stage 1 decides every lane's bytes, never touches f64; any other
+ * wave takes the general path below, which starts again from the f64 distance.  Same bytes either way. */
+template <typename T>
+__device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, T r2, T i2, uint32_t iters_u,
+                                             const double *lds_tab, const uint32_t *palette, uint8_t out[3]) {
+    double dist;
+    if constexpr (sizeof(T) == 8) {
+        dist = (double)(r2 + i2);
+    } else {
+        if (c.filter32 && c.smooth && palette == nullptr) { /* wave-uniform */
+            const float d32 = r2 + i2;
+            const bool sure = d32 >= c.filt_lo32 && d32 <= 0x1.ffffep119f;
+            if (__ballot(!sure) == 0ull) {
+                float nu32;
+                const bool decided = colour_filter_stage1(c, d32, true, iters_u, nu32, out);
+                if (__ballot(!decided) == 0ull) return;
+            }
+        }
+        const double zre = (double)re, zim = (double)im;
+        dist = zre * zre + zim * zim;
+    }
+    colour_of(c, dist, iters_u, lds_tab, palette, out);
 }
 
 /* ---- orbit loop: calc/src/lib.rs:245-257 --------------------------------------------------- */
@@ -643,27 +706,27 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
                                              const uint32_t *s_pal, double sre, double sim, bool valid,
                                              uint32_t cx, uint32_t r, uint32_t lane, uint32_t r_out,
                                              int strip_scalable = -1) {
-    double zre = 0.0, zim = 0.0, dist = 0.0;
+    double zre = 0.0, zim = 0.0;
+    T tre = 0, tim = 0, tr2 = 0, ti2 = 0; /* the final position and its squares in the render's own type */
     uint32_t iters = 0;
     const bool escape_algo = p.algo == 0 /* Mandelbrot */ || p.algo == 2 /* Julia */;
     if (valid && escape_algo) {
         const double cre = p.algo == 0 ? sre : p.julia_re; /* calc/src/lib.rs:209-210 */
         const double cim = p.algo == 0 ? sim : p.julia_im;
         if constexpr (sizeof(T) == 8) {
-            double r2, i2;
-            zre = sre;
-            zim = sim;
-            iters = orbit_auto<double>(p.loop_mode, p.iterations, zre, zim, cre, cim, p.limit * p.limit, p.skip_t,
-                                       r2, i2, strip_scalable);
-            dist = r2 + i2; /* pos.squared_distance(), :214 */
+            tre = sre;
+            tim = sim;
+            iters = orbit_auto<double>(p.loop_mode, p.iterations, tre, tim, cre, cim, p.limit * p.limit, p.skip_t,
+                                       tr2, ti2, strip_scalable);
+            zre = tre;
+            zim = tim;
         } else {
-            float fre = (float)sre, fim = (float)sim, r2, i2;
+            tre = (float)sre, tim = (float)sim;
             const float lim = (float)p.limit;
-            iters = orbit_auto<float>(p.loop_mode, p.iterations, fre, fim, (float)cre, (float)cim, lim * lim,
-                                      (float)p.skip_t, r2, i2, strip_scalable);
-            zre = (double)fre;
-            zim = (double)fim;
-            dist = zre * zre + zim * zim;
+            iters = orbit_auto<float>(p.loop_mode, p.iterations, tre, tim, (float)cre, (float)cim, lim * lim,
+                                      (float)p.skip_t, tr2, ti2, strip_scalable);
+            zre = (double)tre;
+            zim = (double)tim;
         }
     }
 
@@ -672,7 +735,7 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
             uint8_t rgb[3] = {0, 0, 0};
             if (escape_algo) {
                 const ColourConsts cc = make_colour_consts(p);
-                colour_of(cc, dist, iters, s_tab, s_pal, rgb);
+                colour_pixel<T>(cc, tre, tim, tr2, ti2, iters, s_tab, s_pal, rgb); /* :214-234 */
             }
             store_pixel(p, out.rgb, r_out, cx, rgb);
         }
@@ -1019,15 +1082,8 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         if (valid && !handed_over) {
             FR_COLD_PARAMS(kp);
             const ColourConsts cc = make_colour_consts(*kp);
-            double dist;
-            if constexpr (sizeof(T) == 8) {
-                dist = (double)(r2 + i2); /* pos.squared_distance(), :214 */
-            } else {
-                const double zre = (double)re, zim = (double)im;
-                dist = zre * zre + zim * zim;
-            }
             uint8_t rgb[3];
-            colour_of(cc, dist, iters, s_tab, s_pal, rgb);
+            colour_pixel<T>(cc, re, im, r2, i2, iters, s_tab, s_pal, rgb);
             if (narrow) {
                 uint8_t *o = strip_base + (size_t)((uint32_t)k * 8u * bpp) + (size_t)off_lane;
                 if (bpp == 4u) {
@@ -1623,10 +1679,8 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
         if (mine) {
             FR_COLD_PARAMS(kp);
             const ColourConsts cc = make_colour_consts(*kp);
-            const double zre = (double)re, zim = (double)im;
-            const double dist = sizeof(T) == 8 ? (double)(r2 + i2) : zre * zre + zim * zim; /* pos.squared_distance(), :214 */
             uint8_t rgb[3];
-            colour_of(cc, dist, iters, tab, s_pal, rgb);
+            colour_pixel<T>(cc, re, im, r2, i2, iters, tab, s_pal, rgb);
             store_pixel(kp->ncols, kp->out_rgba, out.rgb, q_py[e], q_px[e], rgb);
         }
         tr_colour++;
@@ -2080,9 +2134,25 @@ __global__ __launch_bounds__(256) void math_probe_kernel(int which, const double
         y = __builtin_sqrt(x);
     else if (which == 3)
         y = (double)sat_u8_dev(x);
+    else if (which == 5) /* the packed cast: (float)x into byte 1 of a word whose other bytes must survive */
+        y = (double)sat_u8_pack<1>((float)x, 0xAABBCCDDu);
     else
         y = x / in[(k + 1) % n];
     out[k] = y;
+}
+
+/* Test hook: the number of f32 bit patterns in [lo, hi] on which the packed cast (sat_u8_pack) and the plain one
+ * (sat_u8_dev) disagree in any byte position. */
+__global__ __launch_bounds__(256) void cast_scan_kernel(uint32_t lo, uint32_t hi, unsigned long long *count) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    unsigned long long bad = 0;
+    for (uint64_t b = (uint64_t)lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; b <= hi; b += stride) {
+        const float f = __builtin_bit_cast(float, (uint32_t)b);
+        const uint32_t want = sat_u8_dev(f);
+        const uint32_t got = sat_u8_pack<2>(f, sat_u8_pack<1>(f, sat_u8_pack<0>(f, 0xFF000000u)));
+        bad += got != (0xFF000000u | want | (want << 8) | (want << 16));
+    }
+    if (bad) atomicAdd(count, bad);
 }
 
 /* Test hook: the colour filter's bracket centre against the f64 path's nu, for EVERY f32 with bit pattern in
@@ -2157,6 +2227,14 @@ hipError_t fr_launch_nu_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hi
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nu_scan_kernel, dim3(256 * 16), dim3(256), 0, stream, lo_bits, hi_bits,
+                       reinterpret_cast<unsigned long long *>(out));
+    return hipGetLastError();
+}
+
+hipError_t fr_launch_cast_scan(uint32_t lo_bits, uint32_t hi_bits, double *out, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cast_scan_kernel, dim3(256 * 16), dim3(256), 0, stream, lo_bits, hi_bits,
                        reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }

@@ -351,7 +351,9 @@ int fr_set_loop_mode(int mode);
 /* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
  * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n], 3: the `as u8` cast —
  * so tests can compare the device's roundings with the host's; which = 4: the colour filter's
- * bracket centre against the f64 nu over EVERY f32 bit pattern in [in[0], in[1]], out[0] = worst error. */
+ * bracket centre against the f64 nu over EVERY f32 bit pattern in [in[0], in[1]], out[0] = worst error;
+ * which = 5: the packed form of the cast ((float)in[k] into byte 1 of the word 0xAABBCCDD, returned whole);
+ * which = 6: the number of f32 bit patterns in [in[0], in[1]] on which the packed and the plain cast differ. */
 int fr_debug_math(int which, const double *in, double *out, size_t n);
 /* Tuning aid: a device buffer of 16 uint64 per persistent wave (8192 waves is enough) to which the work-queue
  * kernel's waves write their start / end times (100 MHz ticks) and work counts; NULL turns it off. */

@@ -94,6 +94,18 @@ def test_device_saturating_cast(fr):
     assert np.array_equal(got, want)
 
 
+def test_device_packed_saturating_cast(fr):
+    """The colour filter's f32 stage casts with v_floor_f32 + v_cvt_pk_u8_f32 (fr_kernels.hip: sat_u8_pack): the
+    same bytes as the plain cast on EVERY f32 bit pattern, in every byte position, other bytes left alone."""
+    got = _debug_math(fr, 6, np.array([0.0, float(0xFFFFFFFF)]))
+    assert got[0] == 0.0, "%d f32 patterns differ" % got[0]
+    x = np.array([0.0, 0.4, 0.5, 0.6, 1.5, 2.5, 127.99999, 254.5, 254.9, 255.0, 255.5, 256.0, 1e9, -0.4, -0.6, -1.0, -1e9,
+                  np.nan, np.inf, -np.inf])
+    with np.errstate(invalid="ignore"):
+        want = np.where(np.isnan(x), 0.0, np.clip(np.trunc(x.astype(np.float32).astype(np.float64)), 0, 255))
+    assert np.array_equal(_debug_math(fr, 5, x), 0xAABB00DD + want * 256.0)
+
+
 def test_device_log2_equals_host_soft_log2_and_tracks_libm(fr):
     rng = np.random.default_rng(13)
     x = np.concatenate([
