@@ -219,6 +219,61 @@ def test_two_pass_render_matches_the_oracle(fr, lib, case):
             lib.fr_debug_set_two_pass_capacity(0)
 
 
+def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, lib):
+    """Five host threads, each on its own stream, render Julia images large enough for the default dispatch to
+    take two passes (>= 65 536 tiles): they contend for the context's three survivor-list buffers and sixteen
+    counter slots.  Then the host-buffer entry point, which renders the image in bands on two streams."""
+    import threading
+
+    import torch
+    from fractal_renderer_amd import _native
+
+    ocfgs = [O.cli_config(2048, 2048, O.JULIA, julia_set=js, iterations=it)
+             for js, it in (((-0.8, 0.156), 600), ((0.285, 0.01), 300), ((-0.4, 0.6), 900), ((-0.8, 0.156), 150), ((0.0, 0.8), 500))]
+    cfgs = [to_fr(fr, c) for c in ocfgs]
+    precs = [0, 1, 0, 1, 0]
+    want = []
+    for cfg, prec in zip(cfgs, precs):  # the strip kernel, serially
+        want.append(torch.from_numpy(fr.get_image_rows(cfg, 0, 2048, prec, opts=fr.RenderOpts(tile=8))).cuda().reshape(-1))
+    errs = []
+
+    def work(i):
+        try:
+            dev = torch.device("cuda", 0)
+            stream = torch.cuda.Stream(dev)
+            out = torch.empty(2048 * 2048 * 3, dtype=torch.uint8, device=dev)
+            name = C.create_string_buffer(160)
+            _native.check(lib.fr_set_profiling(1))
+            for rep in range(12):
+                with torch.cuda.stream(stream):
+                    out.zero_()
+                    _native.check(lib.fr_render_rows_rgb8_device(C.byref(cfgs[i]), precs[i], 0, 2048, out.data_ptr(), out.numel(),
+                                                                 stream.cuda_stream))
+                stream.synchronize()
+                _native.check(lib.fr_last_kernel_name(name, len(name)))
+                if not name.value.startswith(b"escape_first_kernel"):
+                    errs.append("thread %d: %r ran" % (i, name.value))
+                    return
+                if not torch.equal(out, want[i]):
+                    errs.append("thread %d rep %d: mismatch" % (i, rep))
+                    return
+            _native.check(lib.fr_set_profiling(0))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cfgs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    # the host-buffer path: the 64 MiB bands of an 8192 x 5000 Julia image on alternating streams, each band two passes
+    ocfg = O.cli_config(8192, 5000, O.JULIA, julia_set=(-0.8, 0.156), iterations=700)
+    cfg = to_fr(fr, ocfg)
+    img = fr.get_image(cfg)
+    total, npx, sample = O.sample_image(ocfg, 8, 8)
+    assert np.array_equal(img[::8, ::8], sample)
+    assert np.array_equal(img, fr.get_image_rows(cfg, 0, 5000, 0, opts=fr.RenderOpts(tile=8)))
+
+
 @pytest.mark.parametrize("tile", [10, 11])
 def test_work_queue_kernel_row_bands_rgba_and_in_place_blocks(fr, lib, tile):
     import torch
