@@ -203,66 +203,103 @@ int Ctx::event(size_t k, hipEvent_t *out) {
     return FR_OK;
 }
 
+/* Both rings: a slot is `busy` from acquire to release (a thread is enqueueing work that uses it) and `pending`
+ * from release until the event recorded behind that work has been waited for.  A caller that finds every slot
+ * busy waits for a release; the waits on events and the allocations happen outside the lock. */
 int Ctx::acquire_palette(PaletteSlot **out) {
-    std::lock_guard<std::mutex> lk(palette_mu);
-    for (int tries = 0; tries < kPaletteSlots; tries++) {
-        PaletteSlot &s = palette_slots[palette_next++ % kPaletteSlots];
-        if (s.busy) continue; /* another thread is between acquire and its event record */
-        if (!s.dev) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * (FR_MAX_PALETTE_ENTRIES + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE)));
-            HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    PaletteSlot *s = nullptr;
+    bool pending;
+    {
+        std::unique_lock<std::mutex> lk(palette_mu);
+        while (!s) {
+            for (int tries = 0; tries < kPaletteSlots && !s; tries++) {
+                PaletteSlot &c = palette_slots[palette_next++ % kPaletteSlots];
+                if (!c.busy) s = &c;
+            }
+            if (!s) slot_cv.wait(lk);
         }
-        if (s.pending) {
-            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if 16 renders are in flight */
-            s.pending = false;
-        }
-        s.busy = true;
-        *out = &s;
-        return FR_OK;
+        s->busy = true;
+        pending = s->pending;
+        s->pending = false;
     }
-    return fail(FR_ERR_HIP, "no palette slot available");
+    hipError_t e = hipSuccess;
+    if (!s->dev) {
+        e = hipMalloc(reinterpret_cast<void **>(&s->dev), sizeof(uint32_t) * (FR_MAX_PALETTE_ENTRIES + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    }
+    if (e == hipSuccess && pending) e = hipEventSynchronize(s->done); /* blocks only if 16 renders are in flight */
+    if (e != hipSuccess) {
+        {
+            std::lock_guard<std::mutex> lk(palette_mu);
+            s->busy = false;
+        }
+        slot_cv.notify_one();
+        return fail_hip(e, "palette slot");
+    }
+    *out = s;
+    return FR_OK;
 }
 
 /* the slot may be reused once everything enqueued so far on `stream` has run */
 void Ctx::release_palette(PaletteSlot *slot, hipStream_t st) {
     if (!slot) return;
-    const bool recorded = hipEventRecord(slot->done, st) == hipSuccess;
+    const bool recorded = slot->done && hipEventRecord(slot->done, st) == hipSuccess;
     if (!recorded) (void)hipStreamSynchronize(st); /* no event to wait on later: wait now */
-    std::lock_guard<std::mutex> lk(palette_mu);
-    slot->pending = recorded;
-    slot->busy = false;
+    {
+        std::lock_guard<std::mutex> lk(palette_mu);
+        slot->pending = recorded;
+        slot->busy = false;
+    }
+    slot_cv.notify_one();
 }
 
 int Ctx::acquire_surv(size_t bytes, SurvSlot **out) {
-    std::lock_guard<std::mutex> lk(palette_mu);
-    for (int tries = 0; tries < kSurvSlots; tries++) {
-        SurvSlot &s = surv_slots[surv_next++ % kSurvSlots];
-        if (s.busy) continue;
-        if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        if (s.pending) {
-            HIP_TRY(hipEventSynchronize(s.done)); /* blocks only if three two-pass renders are in flight */
-            s.pending = false;
+    SurvSlot *s = nullptr;
+    bool pending;
+    {
+        std::unique_lock<std::mutex> lk(palette_mu);
+        while (!s) {
+            for (int tries = 0; tries < kSurvSlots && !s; tries++) {
+                SurvSlot &c = surv_slots[surv_next++ % kSurvSlots];
+                if (!c.busy) s = &c;
+            }
+            if (!s) slot_cv.wait(lk); /* more renders being enqueued at once than there are buffers */
         }
-        if (s.cap < bytes) {
-            if (s.dev) HIP_TRY(hipFree(s.dev));
-            s.dev = nullptr, s.cap = 0;
-            HIP_TRY(hipMalloc(&s.dev, bytes));
-            s.cap = bytes;
-        }
-        s.busy = true;
-        *out = &s;
-        return FR_OK;
+        s->busy = true;
+        pending = s->pending;
+        s->pending = false;
     }
-    return fail(FR_ERR_HIP, "no survivor-list slot available");
+    hipError_t e = hipSuccess;
+    if (!s->done) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    if (e == hipSuccess && pending) e = hipEventSynchronize(s->done); /* the buffer's previous render */
+    if (e == hipSuccess && s->cap < bytes) {
+        if (s->dev) e = hipFree(s->dev);
+        s->dev = nullptr, s->cap = 0;
+        if (e == hipSuccess) e = hipMalloc(&s->dev, bytes);
+        if (e == hipSuccess) s->cap = bytes;
+    }
+    if (e != hipSuccess) {
+        {
+            std::lock_guard<std::mutex> lk(palette_mu);
+            s->busy = false;
+        }
+        slot_cv.notify_one();
+        return fail_hip(e, "survivor-list buffer");
+    }
+    *out = s;
+    return FR_OK;
 }
 
 void Ctx::release_surv(SurvSlot *slot, hipStream_t st) {
     if (!slot) return;
-    const bool recorded = hipEventRecord(slot->done, st) == hipSuccess;
+    const bool recorded = slot->done && hipEventRecord(slot->done, st) == hipSuccess;
     if (!recorded) (void)hipStreamSynchronize(st);
-    std::lock_guard<std::mutex> lk(palette_mu);
-    slot->pending = recorded;
-    slot->busy = false;
+    {
+        std::lock_guard<std::mutex> lk(palette_mu);
+        slot->pending = recorded;
+        slot->busy = false;
+    }
+    slot_cv.notify_one();
 }
 
 namespace {

@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -86,6 +87,7 @@ struct Ctx {
     PaletteSlot palette_slots[kPaletteSlots];
     SurvSlot surv_slots[kSurvSlots];
     std::mutex palette_mu; /* guards both rings */
+    std::condition_variable slot_cv; /* a slot of either ring was released */
     unsigned palette_next = 0, surv_next = 0;
 
     int create(int device); /* hipSetDevice + streams; the calling thread stays on `device` */
