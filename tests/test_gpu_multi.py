@@ -111,6 +111,31 @@ def test_multi_full_size_c2_shape_three_logical_devices(fr):
     assert np.array_equal(got[::64, ::64], colours)
 
 
+def test_multi_large_julia_takes_two_passes_per_device_chunk(fr, lib):
+    """A Julia image whose per-device chunks are large enough (>= 65 536 tiles) for the default dispatch to render
+    them in two passes: survivor lists per chunk, results written at their image rows; host buffer and device gather."""
+    import torch
+    from fractal_renderer_amd import _native
+
+    fr.init_devices([0, 0])
+    cfg, ocfg = cfg_of(fr, 16384, 8192, 300, algo=O.JULIA, julia_set=(-0.8, 0.156))
+    got = fr.get_image_multi(cfg)
+    total, npx, colours = O.sample_image(ocfg, 32, 32, O.F64, 0)
+    assert np.array_equal(got[::32, ::32], colours)
+    single = torch.empty(8192 * 16384 * 3, dtype=torch.uint8, device="cuda:0")
+    s = torch.cuda.current_stream()
+    o = fr.RenderOpts(tile=8)  # the strip kernel
+    _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), 0, 0, 8192, single.data_ptr(), single.numel(), s.cuda_stream,
+                                                      C.byref(o)))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.from_numpy(got).reshape(-1), single.cpu())
+    d_out = torch.zeros(8192 * 16384 * 3, dtype=torch.uint8, device="cuda:0")
+    _native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 0, _native.FR_GATHER_PEER_COPY, d_out.data_ptr(), d_out.numel()))
+    assert torch.equal(d_out, single)
+    st = fr.multi_stats()
+    assert st["n_devices"] == 2 and sum(st["rows"]) == 8192
+
+
 def test_multi_argument_errors(fr, lib):
     from fractal_renderer_amd import _native
 
