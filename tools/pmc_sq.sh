@@ -6,7 +6,7 @@ TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
-ARGS="--no-extras --steps 5 --warmup 1 $*"
+ARGS="--no-extras --steps 10 --warmup 2 $*"   # the default bench's step counts
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/pmc1" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc1.json" 2> "$OUT/pmc1.err"
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d "$OUT/pmc2" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc2.json" 2> "$OUT/pmc2.err"
