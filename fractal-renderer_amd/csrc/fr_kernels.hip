@@ -946,7 +946,12 @@ typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
 
 template <typename T, int M, int kStripTiles>
 __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, const fr_kout out) {
-    __shared__ double s_tab[(FR_LOG2_N * 3 * 8 > FR_MAX_PALETTE_ENTRIES * 4 ? FR_LOG2_N * 3 * 8 : FR_MAX_PALETTE_ENTRIES * 4) / 8];
+    /* LDS holds the palette only (smooth == false).  The log2 table of the exact colour path is NOT staged here:
+     * with the filter on, one wave in fifty needs it, and a strip of short orbits is three microseconds of work —
+     * 3 KB of loads, LDS writes and a barrier in front of every strip were a measurable part of that.  The table
+     * is read where it lies (device constant data: it stays in L2). */
+    __shared__ uint32_t s_palette[FR_MAX_PALETTE_ENTRIES];
+    const double *const s_tab = &g_log2_tab[0][0];
     typedef typename Pair<T>::type T2;
     const uint32_t lane = threadIdx.x;
     const uint32_t *s_pal = nullptr;
@@ -962,16 +967,12 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         FR_COLD_PARAMS(kp);
         const auto &P = *kp;
         if (P.palette != nullptr) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(s_tab);
             const uint32_t n = P.palette_entries;
             const uint32_t *src = P.palette;
-            for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
-            s_pal = dst;
-        } else if (P.smooth) {
-            const double *gt = &g_log2_tab[0][0];
-            for (uint32_t k = lane; k < FR_LOG2_N * 3; k += 64) s_tab[k] = gt[k];
+            for (uint32_t k = lane; k < n; k += 64) s_palette[k] = src[k];
+            s_pal = s_palette;
+            __syncthreads();
         }
-        __syncthreads();
         row0 = (blockIdx.y + gridDim.y * blockIdx.z) * 8u;
         nrows = P.nrows, ncols = P.ncols;
         if (row0 >= nrows) return;
