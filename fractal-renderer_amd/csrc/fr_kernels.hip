@@ -944,24 +944,37 @@ typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
     KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is argument 0 */ \
     asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay where they are written */
 
-template <typename T, int M, int kStripTiles>
+/* is this coordinate admissible as a start / c component of the scaled loop?  (see lane_is_scalable) */
+template <typename T>
+__device__ __forceinline__ bool coord_is_scalable(bool julia, double coord) {
+    constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
+    const T v = (T)coord;
+    const T av = __builtin_fabs(v);
+    const bool in_range = av >= lo && av <= hi;
+    return julia ? (v == (T)0 || in_range) : in_range; /* Julia: a start component; Mandelbrot: start and c */
+}
+
+/* One wave renders kBands strips of kStripTiles tiles, one below the other: what a workgroup pays once — launch,
+ * the scalar loads of its arguments, the coordinate map's IEEE divisions (one per column and one per row of the
+ * whole block) — is spread over 4 x 7 tiles instead of 7; with orbits this short a 7-tile strip is three
+ * microseconds of work and those fixed costs were a tenth of it. */
+template <typename T, int M, int kStripTiles, int kBands>
 __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, const fr_kout out) {
     /* LDS holds the palette only (smooth == false).  The log2 table of the exact colour path is NOT staged here:
-     * with the filter on, one wave in fifty needs it, and a strip of short orbits is three microseconds of work —
-     * 3 KB of loads, LDS writes and a barrier in front of every strip were a measurable part of that.  The table
-     * is read where it lies (device constant data: it stays in L2). */
+     * with the filter on, one wave in fifty needs it — 3 KB of loads, LDS writes and a barrier in front of every
+     * workgroup were a measurable part of its time.  The table is read where it lies (device constant data: it
+     * stays in L2). */
     __shared__ uint32_t s_palette[FR_MAX_PALETTE_ENTRIES];
     const double *const s_tab = &g_log2_tab[0][0];
     typedef typename Pair<T>::type T2;
+    static_assert(kStripTiles <= 8 && kBands <= 8, "one column / one row coordinate per lane");
     const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t *s_pal = nullptr;
-    uint32_t row0, tile0, ncols, nrows, r_out;
-    double coord_lane, sim;
-    bool strip_scalable;
-    /* where the strip's pixels go: a wave-uniform base and one 32-bit byte offset per lane, computed once — the
-     * general form, (row * ncols + col) * 3 in 64 bits per pixel, is three quarter-rate v_mad_u64_u32 per tile */
-    uint8_t *strip_base;
-    uint32_t off_lane, bpp;
+    uint32_t row0, tile0, ncols, nrows, bpp, lane_pitch;
+    double cols, rows; /* the block's coordinate map: column tile0*8 + lane, row row0 + lane (calc/src/lib.rs:181-197) */
+    bool cols_scalable;
+    unsigned long long bad_rows; /* row lanes whose coordinate the scaled loop may not start from */
     bool narrow; /* the 8 rows of a strip span less than 4 GiB: always, short of a 178-million-pixel-wide image */
     {
         FR_COLD_PARAMS(kp);
@@ -973,51 +986,64 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
             s_pal = s_palette;
             __syncthreads();
         }
-        row0 = (blockIdx.y + gridDim.y * blockIdx.z) * 8u;
+        row0 = (blockIdx.y + gridDim.y * blockIdx.z) * (8u * kBands);
         nrows = P.nrows, ncols = P.ncols;
         if (row0 >= nrows) return;
-        const uint32_t ly = lane >> 3;
         const double width = (double)P.width, height = (double)P.height;
-        /* the strip's coordinate map, as in escape_strip_kernel: column lanes 0-55, row lanes 56-63 */
-        static_assert(kStripTiles <= 7, "lanes 56-63 are the row lanes");
-        const bool row_lane = lane >= 56;
         tile0 = blockIdx.x * kStripTiles;
-        const uint32_t block_rows = P.block_rows, y_first = P.y_first, y_stride = P.y_stride;
-        uint32_t coord_u;
-        if (row_lane) {
-            const uint32_t rr = row0 + (lane - 56);
-            coord_u = y_first + (rr / block_rows) * y_stride + rr % block_rows;
-        } else {
-            coord_u = P.x_first + (tile0 * 8u + lane) * P.x_stride;
-        }
-        coord_lane = coord_to_space((double)coord_u, height, row_lane ? 0.5 : (width / height) / 2.0,
-                                    row_lane ? P.pos_im : P.pos_re, row_lane ? P.scale_im : P.scale_re);
-        sim = __shfl(coord_lane, 56 + ly, 64);
-        uint32_t out_row0 = row0;
-        if (P.out_in_place) out_row0 = y_first + (row0 / block_rows) * y_stride + row0 % block_rows;
-        r_out = out_row0 + ly;
+        const uint32_t block_rows = P.block_rows;
+        const uint32_t x = P.x_first + (tile0 * 8u + lane) * P.x_stride;
+        cols = coord_to_space((double)x, height, (width / height) / 2.0, P.pos_re, P.scale_re);
+        const uint32_t rr = row0 + lane;
+        const uint32_t y = P.y_first + (rr / block_rows) * P.y_stride + rr % block_rows;
+        rows = coord_to_space((double)y, height, 0.5, P.pos_im, P.scale_im);
         bpp = P.out_rgba ? 4u : 3u;
         narrow = (uint64_t)ncols * bpp * 8u <= 0xFFFFFFFFull;
-        off_lane = ly * (ncols * bpp) + (lane & 7u) * bpp;
-        strip_base = out.rgb + ((uint64_t)out_row0 * ncols + (uint64_t)tile0 * 8u) * bpp;
-        const bool relevant = lane >= 56 ? (row0 + (lane - 56) < nrows) : (tile0 * 8u + lane < ncols);
-        strip_scalable = coords_admissible<T>(P.algo == 2, P.julia_re, P.julia_im, coord_lane, relevant);
+        lane_pitch = ly * (ncols * bpp) + lx * bpp; /* this lane's byte offset inside a tile's 8 rows */
+        /* may the block's strips run the scaled loop?  (strip_is_scalable, per band) */
+        const bool is_julia = P.algo == 2;
+        bool c_ok = true;
+        if (is_julia) {
+            constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
+            const T jr = __builtin_fabs((T)P.julia_re), ji = __builtin_fabs((T)P.julia_im);
+            c_ok = jr >= lo && jr <= hi && ji >= lo && ji <= hi;
+        }
+        const bool col_relevant = lane < 8u * kStripTiles && tile0 * 8u + lane < ncols;
+        const bool row_relevant = lane < 8u * kBands && rr < nrows;
+        cols_scalable = c_ok && __ballot(col_relevant && !coord_is_scalable<T>(is_julia, cols)) == 0ull;
+        bad_rows = __ballot(row_relevant && !coord_is_scalable<T>(is_julia, rows));
     }
-    const uint32_t lx = lane & 7u;
-    const uint32_t r = row0 + (lane >> 3);
-    /* what the loops need, held in scalar registers across the strip */
+    /* what the loops need, held in scalar registers across the block */
     const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_keep; /* the host guarantees 0 < k1 < cap */
     const bool julia = p.algo == 2;
     const T jre = (T)p.julia_re, jim = (T)p.julia_im;
     const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
     const T skip_t = (T)p.skip_t;
+
+  for (int band = 0; band < kBands; band++) {
+    const uint32_t rb = row0 + 8u * (uint32_t)band; /* the strip's first row */
+    if (rb >= nrows) break;                         /* wave-uniform */
+    const double sim = __shfl(rows, band * 8 + (int)ly, 64);
+    const bool strip_scalable = cols_scalable && ((bad_rows >> (8 * band)) & 0xFFull) == 0ull;
+    /* where the strip's pixels go: a wave-uniform base and one 32-bit byte offset per lane — the general form,
+     * (row * ncols + col) * 3 in 64 bits per pixel, is three quarter-rate v_mad_u64_u32 per tile.  (In place: the
+     * strip's 8 rows lie in one row block, block_rows % 8 == 0.) */
+    uint32_t out_row0 = rb;
+    {
+        FR_COLD_PARAMS(kp);
+        if (kp->out_in_place) out_row0 = kp->y_first + (rb / kp->block_rows) * kp->y_stride + rb % kp->block_rows;
+    }
+    const uint32_t r_out = out_row0 + ly;
+    uint8_t *const strip_base = out.rgb + ((uint64_t)out_row0 * ncols + (uint64_t)tile0 * 8u) * bpp;
+    const uint32_t off_lane = lane_pitch;
+    const uint32_t r = rb + ly;
     /* neighbouring strips append to different lists */
-    const uint32_t list = (blockIdx.x + 5u * (row0 >> 3)) & (FR_SURV_QUEUES - 1u);
+    const uint32_t list = (blockIdx.x + 5u * (rb >> 3)) & (FR_SURV_QUEUES - 1u);
 
     for (int k = 0; k < kStripTiles; k++) {
         const uint32_t col0 = (tile0 + k) * 8u;
         if (col0 >= ncols) break; /* wave-uniform */
-        const double sre = __shfl(coord_lane, k * 8 + lx, 64);
+        const double sre = __shfl(cols, k * 8 + (int)lx, 64);
         const uint32_t cx = col0 + lx;
         const bool valid = cx < ncols && r < nrows;
         T re = (T)sre, im = (T)sim, r2 = 0, i2 = 0;
@@ -1102,6 +1128,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
             }
         }
     }
+  } /* band */
 }
 
 /* ---- strip kernel with lane refill ------------------------------------------------------------
@@ -1920,17 +1947,17 @@ hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t str
 template <typename T>
 hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
     if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
-    constexpr int kStripTiles = 7;
+    constexpr int kStripTiles = 7, kBands = 4;
     const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
-    const uint64_t row_tiles = ((uint64_t)p.nrows + 7) / 8;
-    const uint64_t gy = row_tiles < 32768 ? row_tiles : 32768;
-    const uint64_t gz = (row_tiles + gy - 1) / gy;
+    const uint64_t row_blocks = ((uint64_t)p.nrows + 8 * kBands - 1) / (8 * kBands);
+    const uint64_t gy = row_blocks < 32768 ? row_blocks : 32768;
+    const uint64_t gz = (row_blocks + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
     if (p.loop_mode == 4)
-        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles>), grid, dim3(64), 0, stream, p, out);
+        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, kBands>), grid, dim3(64), 0, stream, p, out);
     else
-        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles>), grid, dim3(64), 0, stream, p, out);
+        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, kBands>), grid, dim3(64), 0, stream, p, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.loop_mode == 4) return launch_queue_form<T, 4, 1>(p, out, stream);
