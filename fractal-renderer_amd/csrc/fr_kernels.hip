@@ -2211,8 +2211,9 @@ bool fr_wants_work_queue(const fr_kparams &p, int tile) {
     if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
     /* its main loop is the scaled form in blocks of loop_mode iterations, counted in an f32 */
     if (p.loop_mode == 0 || p.iterations >= (1u << 24)) return false;
-    /* only on request: on BASELINE C4 it runs 3.5 ms (f32) / 5.0 ms (f64) against the patch-refill kernel's
-     * 3.1 / 4.6, so the default dispatch for large Julia images stays with patch refill */
+    /* only on request: over a whole image (BASELINE C4) it runs 3.5 ms (f32) / 4.9 ms (f64) against the patch-refill
+     * kernel's 3.1 / 4.5; the default for large Julia images is the two-pass render, whose second pass this kernel
+     * is (fr_wants_two_pass) */
     return tile == 10;
 }
 
