@@ -1057,10 +1057,12 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
              * the strip kernel); then what is left of it goes to the list, with the iterations it has done */
             slow = false;
             bool running = valid;
-            uint32_t done = 0;
+            uint32_t done = 0, len = k1; /* a tile still here after 8 episodes is most likely inside a filled set: from
+                                          * then on every episode is twice the last (up to 8 x k1) — fewer restarts of
+                                          * the loop; a dust's dense tiles keep the short looks that suit them */
             unsigned long long sm;
             for (;;) {
-                const uint32_t n = cap - done < k1 ? cap - done : k1;
+                const uint32_t n = cap - done < len ? cap - done : len;
                 if (running) {
                     const uint32_t it = orbit_scaled<T, M>(n, re, im, cre, cim, squared, skip_t, r2, i2);
                     if (it < n) iters = done + it, running = false; /* escaped: (re, im) = `next`, frozen from here on */
@@ -1074,6 +1076,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                     break;
                 }
                 if ((uint32_t)__builtin_popcountll(sm) < keep) break;
+                if (done >= 8u * k1 && len < 8u * k1) len += len;
             }
             if (sm != 0ull) { /* hand the running lanes over: (re, im) is the position after `done` iterations */
                 FR_COLD_PARAMS(kp);
@@ -1947,17 +1950,27 @@ hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t str
 template <typename T>
 hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
     if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
-    constexpr int kStripTiles = 7, kBands = 4;
+    constexpr int kStripTiles = 7;
     const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
-    const uint64_t row_blocks = ((uint64_t)p.nrows + 8 * kBands - 1) / (8 * kBands);
+    const uint64_t row_tiles = ((uint64_t)p.nrows + 7) / 8;
+    /* Four strips per workgroup share its fixed costs (-1.5 % on the 16384^2 C4 in f64) but leave a quarter of the
+     * workgroups to balance over the chip: at 8192^2 (37 000 of them for 8192 resident waves) C4's dust takes 0.86 ms
+     * instead of 0.72, and filled sets, whose workgroups differ a thousandfold in cost, lose more.  So: only while
+     * at least 131 072 workgroups remain. */
+    const int bands = gx * ((row_tiles + 3) / 4) >= 131072 ? 4 : 1;
+    const uint64_t row_blocks = (row_tiles + bands - 1) / bands;
     const uint64_t gy = row_blocks < 32768 ? row_blocks : 32768;
     const uint64_t gz = (row_blocks + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
-    if (p.loop_mode == 4)
-        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, kBands>), grid, dim3(64), 0, stream, p, out);
+    if (p.loop_mode == 4 && bands == 4)
+        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
+    else if (p.loop_mode == 4)
+        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+    else if (bands == 4)
+        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
     else
-        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, kBands>), grid, dim3(64), 0, stream, p, out);
+        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.loop_mode == 4) return launch_queue_form<T, 4, 1>(p, out, stream);
