@@ -341,8 +341,8 @@ def run_single(args, torch, fr, lib, native):
     if is_c2:
         out["other_configs"] = {
             "C3": other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1),
-            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 2),
-            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2),
+            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 3),  # 3 warm-ups: one per survivor-list buffer of the ring
+            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 3),
             "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
         }
         # C5's image (65536^2, 12.9 GB) on ONE device: what each of 8 GPUs would share out; the 8-GPU run is the driver's
