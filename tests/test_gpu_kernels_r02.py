@@ -210,6 +210,10 @@ def test_two_pass_render_matches_the_oracle(fr, lib, case):
         for episode, keep16 in ((4, 1), (8, 16), (64, 12), (200, 8), (1000, 4)):
             got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, refill_minrun=episode, refill_quit16=keep16))
             assert np.array_equal(got, want), (case, prec, episode, keep16)
+        # the shortcut rules the two passes out (the launch takes the patch-refill kernel); no filter / no palette change their colour path
+        for kw in (dict(cycle_shortcut=1), dict(colour_filter=0), dict(palette=0)):
+            got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, **kw))
+            assert np.array_equal(got, want), (case, prec, kw)
         try:  # lists of 64 entries each: nearly everything overflows and is finished by the first pass itself
             lib.fr_debug_set_two_pass_capacity(64)
             for episode in (-1, 8):
