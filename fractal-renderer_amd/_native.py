@@ -135,6 +135,10 @@ PROTOTYPES = {
         C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]),
     "fr_multi_last_stats": (C.c_int, [C.POINTER(fr_multi_stats)]),
     "fr_debug_rccl_selftest": (C.c_int, [C.c_size_t]),
+    "fr_debug_rccl_probe": (C.c_int, []),
+    "fr_debug_inject_multi_failure": (C.c_int, [C.c_int, C.c_int]),
+    "fr_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "fr_unpin_host_buffer": (C.c_int, [C.c_void_p]),
     "fr_last_kernel_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "fr_set_colour_filter": (C.c_int, [C.c_int]),
     "fr_init": (C.c_int, [C.c_int]),

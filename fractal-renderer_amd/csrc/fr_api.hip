@@ -1121,8 +1121,10 @@ int fr_set_loop_mode(int mode) {
     return FR_OK;
 }
 
-/* tuning aid: device buffer (8 u64 per persistent wave, >= 64 KiB x 8) the work-queue kernel's waves write
- * their start / end time and work counts to; NULL = off */
+/* tuning aid: device buffer the work-queue kernel's waves write their start / end time, work counts and per-phase
+ * cycles to — 16 u64 (128 bytes) per persistent wave, at most 32 waves per CU (8192 waves, 1 MiB, on this
+ * device); NULL = off.  The buffer must stay allocated until the pointer has been reset to NULL and the renders
+ * that saw it have finished. */
 int fr_debug_set_queue_trace(void *d_trace) {
     g_queue_trace.store(static_cast<unsigned long long *>(d_trace));
     return FR_OK;

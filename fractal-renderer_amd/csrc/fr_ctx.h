@@ -145,7 +145,9 @@ class ChunkPinner {
     size_t chunks() const { return bounds_.size() - 1; }
     size_t bound(size_t k) const { return bounds_[k]; } /* chunk k = bytes [bound(k), bound(k + 1)) */
     size_t chunk_of(size_t byte) const;
-    bool pin(size_t k); /* waits for the chunk's first touch, pins it once; false: it cannot be pinned (plain copy) */
+    /* waits for the chunk's first touch, pins it once; false: it cannot be pinned (plain copy).  Different chunks
+     * may be pinned from different threads at the same time (fr_multi.hip's pool); one chunk by one thread. */
+    bool pin(size_t k);
     /* the chunks in address order: pins the next one, bytes [a, b); returns false when the walk is over */
     bool next(size_t &a, size_t &b, bool &pinned);
     void release(); /* unpin everything (the caller drained its streams first) */
@@ -162,6 +164,7 @@ class ChunkPinner {
     std::unique_ptr<std::atomic<int>[]> state_; /* 0: pages may not exist yet, 1: touched */
     std::vector<char> pinned_;                  /* 0: not tried, 1: pinned, 2: cannot be pinned */
     std::thread toucher_;
+    std::mutex reg_mu_; /* regs_ and the two timers, when chunks are pinned from several threads */
     std::vector<uint8_t *> regs_;
 };
 void prefault(void *ptr, size_t len);

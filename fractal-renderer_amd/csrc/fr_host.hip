@@ -178,15 +178,18 @@ bool ChunkPinner::pin(size_t k) {
     uint8_t *rb = b < need_ ? out_ + b : reinterpret_cast<uint8_t *>((base + b + kPage - 1) & ~(kPage - 1));
     const hipError_t re = hipHostRegister(ra, (size_t)(rb - ra), flags_);
     bool ok = re == hipSuccess;
-    if (ok) {
-        regs_.push_back(ra);
-    } else {
+    if (!ok) {
         (void)hipGetLastError();
-        ok = re == hipErrorHostMemoryAlreadyRegistered; /* the caller pinned it: even better */
+        ok = re == hipErrorHostMemoryAlreadyRegistered; /* the caller pinned it (fr_pin_host_buffer): even better */
+    }
+    const double t2 = now_ms();
+    {
+        std::lock_guard<std::mutex> lk(reg_mu_);
+        if (re == hipSuccess) regs_.push_back(ra);
+        t_touch += t1 - t0;
+        t_reg += t2 - t1;
     }
     pinned_[k] = ok ? 1 : 2;
-    t_touch += t1 - t0;
-    t_reg += now_ms() - t1;
     return ok;
 }
 

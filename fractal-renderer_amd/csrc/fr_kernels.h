@@ -111,8 +111,9 @@ struct fr_kout {
     double *z;
     uint32_t *iters;
     unsigned long long *count;
-    /* tuning aid (fr_debug_set_queue_trace): the work-queue kernel's waves record 8 words each here —
-     * start, end (100 MHz realtime ticks), patches opened, episodes, colour passes, iterations run, 0, 0 */
+    /* tuning aid (fr_debug_set_queue_trace): the work-queue kernel's waves record 16 u64 (128 bytes) each here —
+     * start, end (100 MHz realtime ticks), patches opened, episodes, colour passes, iterations run, cycles per
+     * phase (open | refill << 32, loop | retire << 32, finish), 7 unused */
     unsigned long long *trace;
 };
 

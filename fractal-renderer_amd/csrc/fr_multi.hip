@@ -29,6 +29,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <cstdlib>
 #include <thread>
 
 #include "fr_ctx.h"
@@ -55,6 +56,7 @@ struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -64,24 +66,35 @@ struct Rccl {
 
     int load() {
         if (handle) return FR_OK;
-        /* RTLD_NOLOAD first: a process that already carries RCCL (PyTorch bundles one) must not get a second */
+        /* FR_RCCL_LIBRARY names the library to load instead of searching (tests use it to make the load fail).
+         * RTLD_NOLOAD first: a process that already carries RCCL (PyTorch bundles one) must not get a second */
+        const char *forced = getenv("FR_RCCL_LIBRARY");
         for (int flags : {RTLD_NOW | RTLD_NOLOAD, RTLD_NOW}) {
-            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-                handle = dlopen(name, flags);
-                if (handle) break;
+            if (forced && *forced) {
+                handle = dlopen(forced, flags);
+            } else {
+                for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                    handle = dlopen(name, flags);
+                    if (handle) break;
+                }
             }
             if (handle) break;
         }
-        if (!handle) return fail(FR_ERR_HIP, std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"));
+        if (!handle) {
+            const char *m = dlerror(); /* ONE call: it clears the message it returns */
+            return fail(FR_ERR_HIP, std::string("cannot load librccl: ") + (m ? m : "not found"));
+        }
         auto sym = [&](const char *n) { return dlsym(handle, n); };
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(sym("ncclCommAbort")); /* optional */
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
         if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+            dlclose(handle);
             handle = nullptr;
             return fail(FR_ERR_HIP, "librccl lacks a required symbol");
         }
@@ -92,10 +105,28 @@ struct Rccl {
         return fail(FR_ERR_HIP, std::string(what) + ": " + GetErrorString(r));
     }
     void destroy_comms() {
+        std::lock_guard<std::mutex> lk(comm_mu);
         for (ncclComm_t c : comms)
             if (c) (void)CommDestroy(c);
         comms.clear();
+        aborted = false;
     }
+    /* A rank failed in the middle of a gather: its peers are (or will be) waiting in device-side receives /
+     * sends that it will never match.  ncclCommAbort is the call RCCL provides for exactly this — it may be
+     * made from any thread and releases the operations in flight on that communicator.  Every communicator
+     * of the set is aborted once; run_multi() drops them afterwards and the next RCCL render makes new ones. */
+    void abort_all() {
+        std::lock_guard<std::mutex> lk(comm_mu);
+        if (aborted) return;
+        aborted = true;
+        for (ncclComm_t &c : comms) {
+            if (!c) continue;
+            if (CommAbort) (void)CommAbort(c);
+            c = nullptr; /* aborted communicators are gone (without ncclCommAbort: leaked rather than hung on) */
+        }
+    }
+    std::mutex comm_mu;
+    bool aborted = false;
 };
 
 /* ---- one worker thread per logical device ----------------------------------------------------- */
@@ -194,6 +225,75 @@ std::vector<std::pair<uint32_t, uint32_t>> chunk_schedule(uint32_t nb) {
 
 enum class Sink { Host, PeerCopy, Rccl };
 
+/* Host sink: the caller's buffer is made DMA-able in page-aligned 64 MiB chunks, front to back (every device's
+ * blocks advance through the image together), by a small pool of threads — hipHostRegister of touched memory
+ * takes ~0.9 ms per 64 MiB on one thread (72 GB/s: 1.3 PCIe links' worth; tools/ubench/host_path.hip measures
+ * how it scales with threads) — while the devices render.  Device threads sleep on a condition variable until
+ * the chunks under their block are pinned. */
+struct PinProgress {
+    ChunkPinner pinner;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<char> state; /* per chunk: 0 pending, 1 pinned, 2 cannot be pinned */
+    bool failed = false;
+    std::atomic<size_t> next{0};
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> pool;
+
+    static int threads() {
+        static const int n = [] {
+            const char *e = getenv("FR_PIN_THREADS");
+            if (e && atoi(e) > 0) return atoi(e) > 16 ? 16 : atoi(e);
+            return 4;
+        }();
+        return n;
+    }
+    PinProgress(uint8_t *dst, size_t need) : pinner(dst, need, true), state(pinner.chunks(), 0) {
+        const size_t n = pinner.chunks();
+        const int T = (int)std::min<size_t>((size_t)threads(), n);
+        for (int t = 0; t < T; t++)
+            pool.emplace_back([this, n] {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= n || stop.load(std::memory_order_acquire)) break;
+                    const bool ok = pinner.pin(k);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        state[k] = ok ? 1 : 2;
+                        if (!ok) failed = true;
+                    }
+                    cv.notify_all();
+                    if (!ok) break;
+                }
+            });
+    }
+    /* sleeps until bytes [a, b) are pinned; false = some chunk cannot be pinned (plain copies) or `abort` was set */
+    bool wait_for(size_t a, size_t b, const std::atomic<bool> &abort) {
+        const size_t k0 = pinner.chunk_of(a), k1 = pinner.chunk_of(b - 1);
+        std::unique_lock<std::mutex> lk(m);
+        bool ready = false;
+        cv.wait(lk, [&] {
+            if (failed || abort.load(std::memory_order_acquire)) return true;
+            for (size_t k = k0; k <= k1; k++)
+                if (state[k] != 1) return false;
+            return ready = true;
+        });
+        return ready;
+    }
+    void wake() {
+        std::lock_guard<std::mutex> lk(m);
+        cv.notify_all();
+    }
+    /* the devices have drained their streams: stop pinning what nobody will use, then unpin everything */
+    void finish() {
+        stop.store(true, std::memory_order_release);
+        for (auto &t : pool) t.join();
+        pool.clear();
+        pinner.release();
+    }
+    ~PinProgress() { finish(); }
+};
+
 struct Job {
     const fr_config *cfg;
     int precision;
@@ -203,11 +303,14 @@ struct Job {
     uint8_t *dst; /* host buffer, or the image in the first device's memory */
     size_t dst_len;
     int root_device;
-    /* Host sink: bytes [0, pinned_upto) of dst are DMA-able; pin_failed = use plain copies */
-    std::atomic<size_t> *pinned_upto;
-    std::atomic<bool> *pin_failed;
+    PinProgress *pins; /* Host sink only */
     DeviceSet *set;
+    std::atomic<bool> *abort; /* a device failed: the others stop starting new work (RCCL: no new groups) */
 };
+
+/* test aid (fr_debug_inject_multi_failure): logical device `g_inject_device` fails before its chunk
+ * `g_inject_chunk` of the next multi-device render, once */
+std::atomic<int> g_inject_device{-1}, g_inject_chunk{0};
 
 void block_range(const Job &j, uint32_t b, uint32_t &y0, uint32_t &y1) {
     y0 = b * j.block_rows;
@@ -239,7 +342,26 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     std::vector<std::pair<size_t, size_t>> deferred; /* (dst offset, scratch offset) of blocks to copy unpinned */
     std::vector<size_t> deferred_len;
 
+#define HIP_BRK(expr)                          \
+    {                                          \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess) {                \
+            rc = ::fr::fail_hip(e_, #expr);    \
+            break;                             \
+        }                                      \
+    }
+    /* Every exit from this loop falls through to the drain below (kernels and DMAs of earlier chunks may be in
+     * flight on three streams into memory the caller frees when we return): no `return` in here. */
     for (size_t c = 0; c < chunks.size() && rc == FR_OK; c++) {
+        if (j.abort->load(std::memory_order_acquire)) {
+            rc = fail(FR_ERR_HIP, "another device of the set failed");
+            break;
+        }
+        if (g_inject_device.load() == (int)r && g_inject_chunk.load() == (int)c) {
+            g_inject_device.store(-1);
+            rc = fail(FR_ERR_HIP, "injected failure (fr_debug_inject_multi_failure)");
+            break;
+        }
         const uint32_t j0 = chunks[c].first, j1 = chunks[c].second;
         uint32_t first = 0, count = 0;
         for (uint32_t k = j0; k < j1; k++) {
@@ -257,7 +379,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             rc = w.timing_event(2 * nkernels, &t0);
             if (rc == FR_OK) rc = w.timing_event(2 * nkernels + 1, &t1);
             if (rc != FR_OK) break;
-            HIP_TRY(hipEventRecord(t0, stream));
+            HIP_BRK(hipEventRecord(t0, stream));
             uint64_t rows = 0;
             if (in_place)
                 rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, n, count, 1, j.dst, j.dst_len,
@@ -266,12 +388,12 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
                 rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, n, count, 0,
                                          scratch + local_off, (size_t)(my_rows * row_bytes - local_off), stream, &rows);
             if (rc != FR_OK) break;
-            HIP_TRY(hipEventRecord(t1, stream));
+            HIP_BRK(hipEventRecord(t1, stream));
             nkernels++;
             local_off += in_place ? 0 : rows * row_bytes;
             rc = ctx.event(c, &done);
             if (rc != FR_OK) break;
-            HIP_TRY(hipEventRecord(done, stream));
+            HIP_BRK(hipEventRecord(done, stream));
         }
         /* ---- move chunk c while chunk c+1 renders */
         if (j.sink == Sink::Rccl) {
@@ -292,7 +414,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
                 int rc2 = rc_lib.check(rc_lib.GroupEnd(), "ncclGroupEnd");
                 if (rc == FR_OK) rc = rc2;
             } else if (count) {
-                HIP_TRY(hipStreamWaitEvent(ctx.copy_stream, done, 0));
+                HIP_BRK(hipStreamWaitEvent(ctx.copy_stream, done, 0));
                 rc = rc_lib.check(rc_lib.GroupStart(), "ncclGroupStart");
                 size_t off = chunk_off;
                 for (uint32_t k = 0; k < count && rc == FR_OK; k++) {
@@ -308,23 +430,25 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             continue;
         }
         if (!count || in_place) continue;
-        HIP_TRY(hipStreamWaitEvent(ctx.copy_stream, done, 0));
+        HIP_BRK(hipStreamWaitEvent(ctx.copy_stream, done, 0));
         size_t off = chunk_off;
-        for (uint32_t k = 0; k < count; k++) {
+        for (uint32_t k = 0; k < count && rc == FR_OK; k++) {
             uint32_t y0, y1;
             block_range(j, first + k * n, y0, y1);
             const size_t bytes = row_bytes * (y1 - y0), dst_off = row_bytes * y0;
             if (j.sink == Sink::PeerCopy) {
-                if (ctx.hip_device == j.root_device)
-                    HIP_TRY(hipMemcpyAsync(j.dst + dst_off, scratch + off, bytes, hipMemcpyDeviceToDevice, ctx.copy_stream));
-                else
-                    HIP_TRY(hipMemcpyPeerAsync(j.dst + dst_off, j.root_device, scratch + off, ctx.hip_device, bytes,
+                if (ctx.hip_device == j.root_device) {
+                    HIP_BRK(hipMemcpyAsync(j.dst + dst_off, scratch + off, bytes, hipMemcpyDeviceToDevice, ctx.copy_stream));
+                } else {
+                    HIP_BRK(hipMemcpyPeerAsync(j.dst + dst_off, j.root_device, scratch + off, ctx.hip_device, bytes,
                                                ctx.copy_stream));
+                }
             } else {
-                /* the main thread pins the buffer front to back while we render: wait for this block's bytes */
-                while (!plain_copies && j.pinned_upto->load(std::memory_order_acquire) < dst_off + bytes) {
-                    if (j.pin_failed->load(std::memory_order_acquire)) plain_copies = true;
-                    else std::this_thread::yield();
+                /* the pinner makes the buffer DMA-able front to back while we render: wait for this block's bytes */
+                if (!plain_copies && !j.pins->wait_for(dst_off, dst_off + bytes, *j.abort)) plain_copies = true;
+                if (j.abort->load(std::memory_order_acquire)) {
+                    rc = fail(FR_ERR_HIP, "another device of the set failed");
+                    break;
                 }
                 if (plain_copies) {
                     deferred.emplace_back(dst_off, off);
@@ -332,11 +456,11 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
                 } else {
                     /* one DMA must not span two pins: split the block where the pinner's chunks end */
                     size_t done_b = 0;
-                    while (done_b < bytes) {
+                    while (done_b < bytes && rc == FR_OK) {
                         size_t ca = 0, cb = 0; /* the chunk [ca, cb) that holds byte dst_off + done_b */
                         while ((cb = ChunkPinner::chunk_end(j.dst, need_total, ca)) <= dst_off + done_b) ca = cb;
                         const size_t part = std::min(bytes - done_b, cb - (dst_off + done_b));
-                        HIP_TRY(hipMemcpyAsync(j.dst + dst_off + done_b, scratch + off + done_b, part, hipMemcpyDeviceToHost,
+                        HIP_BRK(hipMemcpyAsync(j.dst + dst_off + done_b, scratch + off + done_b, part, hipMemcpyDeviceToHost,
                                                ctx.copy_stream));
                         done_b += part;
                     }
@@ -344,6 +468,13 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             }
             off += bytes;
         }
+    }
+#undef HIP_BRK
+    if (rc != FR_OK) {
+        /* tell the others, and — RCCL — release the peers that wait for transfers this device will never post */
+        j.abort->store(true, std::memory_order_release);
+        j.pins->wake();
+        if (j.sink == Sink::Rccl) rc_lib.abort_all();
     }
     /* drain, error or not */
     hipError_t e1 = hipStreamSynchronize(ctx.stream);
@@ -401,30 +532,18 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
         rc = ensure_rccl(*set);
         if (rc != FR_OK) return rc;
     }
-    std::atomic<size_t> pinned_upto{0};
-    std::atomic<bool> pin_failed{false};
+    std::atomic<bool> abort{false};
+    /* Host sink: while the devices render, a pool makes the caller's buffer DMA-able front to back */
+    std::unique_ptr<PinProgress> pins;
+    if (sink == Sink::Host) pins.reset(new PinProgress(dst, need));
     Job job{cfg, precision, default_opts(), block_rows, (uint32_t)(((uint64_t)cfg->height + block_rows - 1) / block_rows), n, sink,
-            dst, dst_len, set->devices[0], &pinned_upto, &pin_failed, set};
+            dst, dst_len, set->devices[0], pins.get(), set, &abort};
     fr_multi_stats stats;
     memset(&stats, 0, sizeof stats);
     stats.n_devices = n;
     for (auto &w : set->workers) {
         Worker *wp = w.get();
         wp->post([wp, &job, &stats] { return device_job(*wp, job, &stats); });
-    }
-    /* Host sink: while the devices render, make the caller's buffer DMA-able front to back */
-    std::unique_ptr<ChunkPinner> pinner;
-    if (sink == Sink::Host) {
-        pinner.reset(new ChunkPinner(dst, need, true));
-        size_t a, b;
-        bool pinned;
-        while (pinner->next(a, b, pinned)) {
-            if (!pinned) {
-                pin_failed.store(true, std::memory_order_release);
-                break;
-            }
-            pinned_upto.store(b, std::memory_order_release);
-        }
     }
     std::string first_err;
     for (auto &w : set->workers) {
@@ -434,7 +553,8 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
             first_err = "device " + std::to_string(w->index) + ": " + w->err;
         }
     }
-    if (pinner) pinner->release();
+    if (pins) pins->finish(); /* every device has drained its streams */
+    if (sink == Sink::Rccl && abort.load()) set->rccl.destroy_comms(); /* aborted: the next RCCL render makes new ones */
     stats.wall_ms = now_ms() - t_start;
     tl_stats = stats;
     if (rc != FR_OK) return fail(rc, first_err);
@@ -554,6 +674,31 @@ int fr_render_rgb8_multi_device(const fr_config *cfg, int precision, uint32_t bl
 int fr_multi_last_stats(fr_multi_stats *stats) {
     if (!stats) return fail(FR_ERR_INVALID_ARGUMENT, "stats is NULL");
     *stats = tl_stats;
+    return FR_OK;
+}
+
+int fr_debug_rccl_probe(void) {
+    Rccl probe; /* a private copy of the loader: nothing of the device set is touched */
+    const int rc = probe.load();
+    if (rc == FR_OK && probe.handle) dlclose(probe.handle);
+    return rc;
+}
+
+int fr_debug_inject_multi_failure(int device_index, int chunk) {
+    g_inject_chunk.store(chunk < 0 ? 0 : chunk);
+    g_inject_device.store(device_index);
+    return FR_OK;
+}
+
+int fr_pin_host_buffer(void *ptr, size_t len) {
+    if (!ptr || len == 0) return fail(FR_ERR_INVALID_ARGUMENT, "ptr is NULL or len is 0");
+    HIP_TRY(hipHostRegister(ptr, len, hipHostRegisterPortable));
+    return FR_OK;
+}
+
+int fr_unpin_host_buffer(void *ptr) {
+    if (!ptr) return fail(FR_ERR_INVALID_ARGUMENT, "ptr is NULL");
+    HIP_TRY(hipHostUnregister(ptr));
     return FR_OK;
 }
 

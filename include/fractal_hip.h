@@ -232,6 +232,24 @@ int fr_multi_last_stats(fr_multi_stats *stats);
 /* Test hook: one grouped self send/recv of `bytes` bytes through RCCL on the set's first device
  * (loads librccl, creates the communicator) — the only RCCL traffic a one-GPU box can carry. */
 int fr_debug_rccl_selftest(size_t bytes);
+/* Test hook: can librccl be loaded and does it export what the RCCL gather needs?  Touches no device (usable
+ * without a GPU).  The environment variable FR_RCCL_LIBRARY, when set, names the library to load instead of the
+ * default search — an unloadable name must yield FR_ERR_HIP and a message, never a crash. */
+int fr_debug_rccl_probe(void);
+/* Test hook: logical device `device_index` of the set fails before its chunk `chunk` of the NEXT multi-device
+ * render (once; -1 disarms).  The render must return an error with every stream drained — no hang, no DMA
+ * left in flight into the caller's buffer — and the render after it must succeed. */
+int fr_debug_inject_multi_failure(int device_index, int chunk);
+
+/* Optional, for callers that render into the SAME host buffer again and again (a GUI's frame buffer,
+ * src/gui.rs:56-82): pin it once.  fr_render_rgb8 / fr_render_rgb8_multi make every large host buffer they are
+ * handed DMA-able for the duration of the call (hipHostRegister, ~0.9 ms per 64 MiB) and release it before they
+ * return; a buffer pinned through this call is found already registered and that cost disappears.  The library
+ * does NOT cache registrations by itself: get_image returns a fresh Vec each call (src/lib.rs:266-267) and a
+ * registration outliving its allocation would pin — and later DMA into — memory that belongs to someone else.
+ * The caller must unpin before freeing.  Portable (valid on every device of the process). */
+int fr_pin_host_buffer(void *ptr, size_t len);
+int fr_unpin_host_buffer(void *ptr);
 
 /* ---- get_image, Algo::BarnsleyFern arm — src/lib.rs:271-319, fern() :417-463 ------------------- */
 

@@ -131,3 +131,26 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".inc")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "fractal_oracle" not in text and "oracle_lib" not in text and "fro_" not in text, f
+
+
+def test_rccl_load_failure_is_an_error_code_not_a_crash():
+    """ADVICE r02: Rccl::load() built its message from two dlerror() calls (the second returns NULL:
+    std::string + NULL crashed exactly when librccl could not be loaded).  Forced here with FR_RCCL_LIBRARY
+    in a child process (the variable is read when the load is attempted; a crash would take pytest down)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import fractal_renderer_amd as fr\n"
+        "from fractal_renderer_amd import _native\n"
+        "lib = _native.load()\n"
+        "rc = lib.fr_debug_rccl_probe()\n"
+        "print('rc', rc, lib.fr_last_error().decode())\n" % ROOT
+    )
+    env = dict(os.environ, FR_RCCL_LIBRARY="/nonexistent/librccl-not-here.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("rc ")][0]
+    assert int(line.split()[1]) == 4, line  # FR_ERR_HIP
+    assert "cannot load librccl" in line and "librccl-not-here" in line, line

@@ -324,3 +324,56 @@ def test_bench_under_the_launcher_at_world_size_one():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e9 and "one process per GPU" in d["config"]["partition"]
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"].startswith("escape_strip_kernel<double")
+
+
+@pytest.mark.parametrize("sink", ["host", "peer"])
+def test_multi_device_failure_drains_and_recovers(fr, lib, sink):
+    """a failure inside device_job's chunk loop used to return straight out of the function with
+    kernels and DMAs in flight into memory the caller frees next.  Injected here on one logical device of three,
+    at its first and at a later chunk: the call must come back with an error (no hang), and the render after it
+    — same set, same buffers — must be byte-identical to the single render."""
+    import torch
+
+    fr.init_devices([0, 0, 0])
+    cfg, _ = cfg_of(fr, 1536, 4096, 180)
+    want = fr.get_image(cfg)
+    for dev, chunk in ((1, 0), (2, 1), (0, 2)):
+        from fractal_renderer_amd import _native
+
+        _native.check(lib.fr_debug_inject_multi_failure(dev, chunk))
+        out = np.zeros((cfg.height, cfg.width, 3), dtype=np.uint8)
+        if sink == "host":
+            rc = lib.fr_render_rgb8_multi(C.byref(cfg), 0, 64, out.ctypes.data, out.nbytes)
+        else:
+            d = torch.zeros(out.nbytes, dtype=torch.uint8, device="cuda")
+            rc = lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 64, 0, C.c_void_p(d.data_ptr()), d.numel())
+        assert rc == 4, (dev, chunk, rc)  # FR_ERR_HIP
+        msg = lib.fr_last_error().decode()
+        assert "device %d" % dev in msg and "injected failure" in msg, msg
+        _native.check(lib.fr_debug_inject_multi_failure(-1, 0))
+        got = fr.get_image_multi(cfg, 0, 64)
+        assert np.array_equal(got, want), (dev, chunk)
+    fr.init_devices([0])
+
+
+def test_multi_host_buffer_pinned_by_the_caller(fr, lib):
+    """fr_pin_host_buffer: a frame buffer that is rendered into again and again is pinned once by its owner; the
+    multi-device and the single-device host renders find it registered and produce the same bytes."""
+    from fractal_renderer_amd import _native
+
+    fr.init_devices([0, 0])
+    cfg, _ = cfg_of(fr, 4096, 4096, 120)
+    want = fr.get_image(cfg)
+    buf = np.zeros((cfg.height, cfg.width, 3), dtype=np.uint8)
+    _native.check(lib.fr_pin_host_buffer(C.c_void_p(buf.ctypes.data), buf.nbytes))
+    try:
+        for _ in range(3):
+            buf[:] = 0
+            fr.get_image_multi(cfg, 0, 0, out=buf)
+            assert np.array_equal(buf, want)
+        buf[:] = 0
+        _native.check(lib.fr_render_rgb8(C.byref(cfg), buf.ctypes.data, buf.nbytes))
+        assert np.array_equal(buf, want)
+    finally:
+        _native.check(lib.fr_unpin_host_buffer(C.c_void_p(buf.ctypes.data)))
+    fr.init_devices([0])

@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# the work-queue kernel's episode policy and variants on C4 (GPU box, from the repo root)
+cd "${GRAFT_REPO_ROOT:-.}"
 python -m pytest tests/test_gpu_kernels_r02.py -x -q -m gpu -k "queue or c4 or kats" 2>&1 | tail -3
 run() { python bench.py --view julia --iterations 4096 --no-extras --steps 10 "$@" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['roofline']['frac'],4), d['roofline']['kernel'][:30])"; }
 for prec in f32 f64; do
