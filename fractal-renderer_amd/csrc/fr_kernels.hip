@@ -30,6 +30,8 @@
  */
 #include "fr_kernels.h"
 
+#include <cstdlib>
+
 #include "fr_math.h"
 
 namespace {
@@ -153,20 +155,27 @@ __device__ __forceinline__ void colour_outside_flat(const ColourConsts &c, uint3
  * checks — keep every step exact enough: iters + 1 converts exactly, nothing under- or overflows.)  Both ends of
  * the window are cast into packed bytes, so one comparison decides all three channels.  Returns, per lane,
  * whether the byte triple is decided (and then out[] holds it). */
-__device__ __forceinline__ bool colour_filter_stage1(const ColourConsts &c, float d32, bool in_range, uint32_t iters_u,
-                                                     float &nu32, uint8_t out[3]) {
+/* itp1 = (float)(iters + 1), exact (iterations < 2^24); `lo` = the bytes r | g << 8 | b << 16 when decided */
+__device__ __forceinline__ bool colour_filter_stage1_packed(const ColourConsts &c, float d32, float itp1, float &nu32,
+                                                            uint32_t &lo) {
     const float l1 = __builtin_amdgcn_logf(d32);
     nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
     const int ch[3] = {0, 2, 1}; /* color_multiply's RGB::new(r, b, g) swap, as in colour_multiply() */
-    const float m32 = ((float)(iters_u + 1u) - nu32) * c.filt_k32;
+    const float m32 = (itp1 - nu32) * c.filt_k32;
     const float v0 = c.prim32[ch[0]] * m32, v1 = c.prim32[ch[1]] * m32, v2 = c.prim32[ch[2]] * m32;
     const float w0 = __builtin_fmaf(__builtin_fabsf(v0), 0x1p-21f, c.filt_d32[ch[0]]);
     const float w1 = __builtin_fmaf(__builtin_fabsf(v1), 0x1p-21f, c.filt_d32[ch[1]]);
     const float w2 = __builtin_fmaf(__builtin_fabsf(v2), 0x1p-21f, c.filt_d32[ch[2]]);
-    const uint32_t lo = sat_u8_pack<2>(v2 - w2, sat_u8_pack<1>(v1 - w1, sat_u8_pack<0>(v0 - w0, 0u)));
+    lo = sat_u8_pack<2>(v2 - w2, sat_u8_pack<1>(v1 - w1, sat_u8_pack<0>(v0 - w0, 0u)));
     const uint32_t hi = sat_u8_pack<2>(v2 + w2, sat_u8_pack<1>(v1 + w1, sat_u8_pack<0>(v0 + w0, 0u)));
+    return lo == hi;
+}
+__device__ __forceinline__ bool colour_filter_stage1(const ColourConsts &c, float d32, bool in_range, uint32_t iters_u,
+                                                     float &nu32, uint8_t out[3]) {
+    uint32_t lo;
+    const bool same = colour_filter_stage1_packed(c, d32, (float)(iters_u + 1u), nu32, lo);
     out[0] = (uint8_t)lo, out[1] = (uint8_t)(lo >> 8), out[2] = (uint8_t)(lo >> 16);
-    return in_range && lo == hi;
+    return in_range && same;
 }
 
 __device__ __forceinline__ bool colour_outside_filtered(const ColourConsts &c, double dist, uint32_t iters_u, uint8_t out[3]) {
@@ -906,6 +915,14 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
     }
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 /* ---- first pass + survivor list (two-pass rendering, part 1) ---------------------------------------
  *
  * C4's orbits (a Julia dust: mean 44 iterations, none near the cap of 4096, 58 % of the pixels gone after 8)
@@ -959,7 +976,7 @@ __device__ __forceinline__ bool coord_is_scalable(bool julia, double coord) {
  * whole block) — is spread over 4 x 7 tiles instead of 7; with orbits this short a 7-tile strip is three
  * microseconds of work and those fixed costs were a tenth of it. */
 template <typename T, int M, int kStripTiles, int kBands>
-__global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, const fr_kout out) {
+__global__ __launch_bounds__(64) void escape_first_v1_kernel(const fr_kparams p, const fr_kout out) {
     /* LDS holds the palette only (smooth == false).  The log2 table of the exact colour path is NOT staged here:
      * with the filter on, one wave in fifty needs it — 3 KB of loads, LDS writes and a barrier in front of every
      * workgroup were a measurable part of its time.  The table is read where it lies (device constant data: it
@@ -1128,6 +1145,499 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                 }
             } else {
                 store_pixel(kp->ncols, kp->out_rgba, out.rgb, r_out, cx, rgb);
+            }
+        }
+    }
+  } /* band */
+}
+
+/* ---- first pass, second form: freeze and finish (round 3) ------------------------------------------
+ *
+ * What the first form above pays around the orbit loop is, on C4, more than the loop itself: per 8x8 tile 364 VALU
+ * instructions of which the loop at its floor is 190, and 150 scalar instructions (profiles/r03_c4_first_pass_isa_classes.txt).
+ * The excess has three sources and this form removes each:
+ *   1. the transit.  Lanes on their way out (|z|^2 between T and limit^2, 4-5 iterations) put the WHOLE wave on the
+ *      fully-checked path (8 VALU + 3 SALU per iteration, a scalar handler per escape event).  Here a lane that
+ *      fails the block-end test |z|^2 <= T simply FREEZES (v_cmpx, as in the work-queue kernel): the wave goes on
+ *      with unchecked blocks (27 VALU per 4 iterations, 3 SALU, a per-lane f32 count instead of every escape-index
+ *      handler) until its episode ends or nobody runs, and the frozen lanes' last few iterations are run ONCE per
+ *      tile, together, by an exact-check loop in the scaled form (9 VALU + the count per iteration; no conversion);
+ *   2. conversions.  The state stays in the scaled form (X = 2re, Y = 2im, A = X^2, B = Y^2) from the pixel's
+ *      start to its colour: the filter's first stage starts from d32 = (A + B) / 4 — the very number
+ *      fl(re^2 + im^2) it used before, scaling by 4 being exact — and its (iters + 1) is the lane's count;
+ *      only a wave that needs the general colour path, and a hand-over, compute re and im;
+ *   3. divergent control.  Which lanes run, froze, escaped or were handed over are 64-bit MASKS in scalar
+ *      registers, set into EXEC inside the asm loops; the code around them is uniform.
+ * Coordinates are narrowed to T once per block, not per tile; 3-byte pixels leave as one 16-bit and one 8-bit
+ * store.  Same bytes: every pixel's orbit is recursive()'s arithmetic whichever loop runs it (the scaled form's
+ * exactness and the choice of T are argued at "orbit loop, scaled form"). */
+template <typename T>
+struct UBits {
+    typedef uint32_t type;
+};
+template <>
+struct UBits<double> {
+    typedef uint64_t type;
+};
+template <typename T>
+__device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t b = fr_bits_of(v);
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+    } else {
+        return (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v));
+    }
+}
+
+/* bit `lane` of a wave-uniform mask, as a per-lane boolean */
+__device__ __forceinline__ bool lane_in(unsigned long long m) {
+    uint32_t b;
+    asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(b) : "s"(m));
+    return b != 0u;
+}
+
+/* Blocks of M unchecked scaled iterations for the lanes of `mask` (a subset of EXEC, not empty), one |z|^2 <= T
+ * test per block: a lane that fails it freezes with the state, t = A + B and count it has at that moment.  Ends after
+ * `nblocks` or when no lane runs; returns the lanes that passed every test. */
+#define FR_FB_ASM(SFX, BLOCK_ITS, STEP)                \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    "s_mov_b64 exec, %[mask]\n"                        \
+    ".Lfb_%=:\n" BLOCK_ITS                             \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_cbranch_execz .Lfbd_%=\n"                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc0 .Lfb_%=\n"                         \
+    ".Lfbd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"
+
+template <typename T, int M>
+__device__ __forceinline__ unsigned long long first_blocks(unsigned long long mask, uint32_t nblocks, T &X, T &Y, T &A, T &B,
+                                                           T &t, float &cnt, T c2re, T c2im, typename UBits<T>::type t4lim) {
+    T q;
+    unsigned long long sorig, srun;
+    uint32_t k = __builtin_amdgcn_readfirstlane(nblocks) - 1u;
+#define FR_FB_OPERANDS                                                                                           \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),            \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(k)                                                      \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask)                                   \
+    : "vcc", "scc"
+    if constexpr (sizeof(T) == 8) {
+        if constexpr (M == 4)
+            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_FB_OPERANDS);
+        else
+            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "2.0") FR_FB_OPERANDS);
+    } else {
+        if constexpr (M == 4)
+            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_FB_OPERANDS);
+        else
+            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_FB_OPERANDS);
+    }
+    return srun;
+}
+
+/* recursive()'s iteration with its escape test after every one, in the scaled form (4 * dist against 4 * limit^2:
+ * the same comparison), for the lanes of `mask` (not empty): v_cmpx freezes a lane at `next`, which is what
+ * recursive() returns; the count runs with the lane.  Ends after `n` iterations or when no lane is left; returns the
+ * lanes that did not escape. */
+#define FR_FS_ASM(SFX)                                 \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    "s_mov_b64 exec, %[mask]\n"                        \
+    ".Lfs_%=:\n" FR_SC_IT(SFX)                         \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_f32 %[cnt], 1.0, %[cnt]\n"                  \
+    "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"               \
+    "s_cbranch_execz .Lfsd_%=\n"                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc0 .Lfs_%=\n"                         \
+    ".Lfsd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"
+
+template <typename T>
+__device__ __forceinline__ unsigned long long finish_scaled(unsigned long long mask, uint32_t n, T &X, T &Y, T &A, T &B, T &t,
+                                                            float &cnt, T c2re, T c2im, typename UBits<T>::type lim4) {
+    T q;
+    unsigned long long sorig, srun;
+    uint32_t k = __builtin_amdgcn_readfirstlane(n) - 1u;
+#define FR_FS_OPERANDS                                                                                           \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),            \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(k)                                                      \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [mask] "s"(mask)                                     \
+    : "vcc", "scc"
+    if constexpr (sizeof(T) == 8)
+        asm volatile(FR_FS_ASM("f64") FR_FS_OPERANDS);
+    else
+        asm volatile(FR_FS_ASM("f32") FR_FS_OPERANDS);
+    return srun;
+}
+
+/* The common case of a tile, start to finish, in one asm block — a full tile of a strip that may use the scaled
+ * form, no start beyond T: the first episode (`nblk` blocks of M unchecked iterations) and, if every lane has
+ * frozen by its end (three tiles in five on C4 are gone after ONE block), their exact last iterations.  The scalar
+ * unit is a co-limiter of the f32 render (one scalar instruction per ~4 cycles per SIMD against ~2.4 for an f32
+ * vector one; profiles/r03_c4_first_pass_classes.txt): on this path the scalar work is the loops' own control
+ * and a dozen instructions besides.  Returns how far it got; the state is valid for the general path to go on from:
+ *   0  every lane escaped (state = `next`, cnt = its index + 1)
+ *   1  lanes still run after the first episode (`srun`): further episodes or a hand-over
+ *   2  nothing was done: some start lies beyond T
+ *   3  64 exact iterations did not finish everybody (`srun` = the lanes still live) */
+#define FR_TILE_ASM(SFX, MOVT, BLOCK_ITS, STEP)        \
+    "v_add_" SFX " %[X], %[sre], %[sre]\n"             \
+    MOVT " %[Y], %[Y0]\n"                              \
+    "v_mul_" SFX " %[A], %[X], %[X]\n"                 \
+    MOVT " %[B], %[B0]\n"                              \
+    "v_mov_b32 %[cnt], 0\n"                            \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "s_mov_b32 %[st], 2\n"                             \
+    "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"           \
+    "s_cbranch_vccnz .Ltout_%=\n"                      \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    ".Ltb_%=:\n" BLOCK_ITS                             \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_cbranch_execz .Ltbd_%=\n"                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc0 .Ltb_%=\n"                         \
+    ".Ltbd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"                       \
+    "s_mov_b32 %[st], 1\n"                             \
+    "s_cmp_lg_u64 %[srun], 0\n"                        \
+    "s_cbranch_scc1 .Ltout_%=\n"                       \
+    "s_mov_b32 %[st], 0\n"                             \
+    "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"               \
+    "s_cbranch_execz .Ltfd_%=\n"                       \
+    "s_mov_b32 %[k], 63\n"                             \
+    ".Ltf_%=:\n" FR_SC_IT(SFX)                         \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_f32 %[cnt], 1.0, %[cnt]\n"                  \
+    "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"               \
+    "s_cbranch_execz .Ltfd_%=\n"                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc0 .Ltf_%=\n"                         \
+    "s_mov_b32 %[st], 3\n"                             \
+    ".Ltfd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"                       \
+    ".Ltout_%=:\n"
+
+template <typename T, int M>
+__device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, T c2re, T c2im, typename UBits<T>::type t4lim,
+                                              typename UBits<T>::type lim4, T &X, T &Y, T &A, T &B, T &t, float &cnt,
+                                              unsigned long long &srun) {
+    T q;
+    unsigned long long sorig;
+    uint32_t st, k = nblk - 1u;
+#define FR_TILE_OPERANDS                                                                                         \
+    : [X] "=&v"(X), [Y] "=&v"(Y), [A] "=&v"(A), [B] "=&v"(B), [t] "=&v"(t), [cnt] "=&v"(cnt), [q] "=&v"(q),      \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(k), [st] "=&s"(st)                                      \
+    : [sre] "v"(sre), [Y0] "v"(Y0), [B0] "v"(B0), [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim),        \
+      [lim4] "s"(lim4)                                                                                           \
+    : "vcc", "scc"
+    if constexpr (sizeof(T) == 8) {
+        if constexpr (M == 4)
+            asm volatile(FR_TILE_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_TILE_OPERANDS);
+        else
+            asm volatile(FR_TILE_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64"), "2.0") FR_TILE_OPERANDS);
+    } else {
+        if constexpr (M == 4)
+            asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_TILE_OPERANDS);
+        else
+            asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_TILE_OPERANDS);
+    }
+    return st;
+}
+
+/* the filter's first stage with its constants held by the caller (scalar registers, loaded once per workgroup) */
+struct Filter32 {
+    float lo, k, p0, p1, p2, d0, d1, d2; /* channels in OUTPUT order (color_multiply's swap applied by the host side of this struct) */
+};
+__device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, float itp1, uint32_t &lo) {
+    const float l1 = __builtin_amdgcn_logf(d32);
+    const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
+    const float m32 = (itp1 - nu32) * f.k;
+    const float v0 = f.p0 * m32, v1 = f.p1 * m32, v2 = f.p2 * m32;
+    const float w0 = __builtin_fmaf(__builtin_fabsf(v0), 0x1p-21f, f.d0);
+    const float w1 = __builtin_fmaf(__builtin_fabsf(v1), 0x1p-21f, f.d1);
+    const float w2 = __builtin_fmaf(__builtin_fabsf(v2), 0x1p-21f, f.d2);
+    lo = sat_u8_pack<2>(v2 - w2, sat_u8_pack<1>(v1 - w1, sat_u8_pack<0>(v0 - w0, 0u)));
+    const uint32_t hi = sat_u8_pack<2>(v2 + w2, sat_u8_pack<1>(v1 + w1, sat_u8_pack<0>(v0 + w0, 0u)));
+    return lo == hi;
+}
+
+template <typename T, int M, int kStripTiles, int kBands>
+__global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, const fr_kout out) {
+    __shared__ uint32_t s_palette[FR_MAX_PALETTE_ENTRIES]; /* smooth == false only; the log2 table stays in L2 (see v1) */
+    const double *const s_tab = &g_log2_tab[0][0];
+    typedef typename Pair<T>::type T2;
+    typedef typename UBits<T>::type UB;
+    static_assert(kStripTiles <= 8 && kBands <= 8, "one column / one row coordinate per lane");
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t *s_pal = nullptr;
+    uint32_t row0, tile0, ncols, nrows, bpp, lane_pitch;
+    T colsT, rowsT; /* the block's coordinate map (calc/src/lib.rs:181-197), narrowed once: column tile0*8 + lane, row row0 + lane */
+    bool cols_scalable;
+    unsigned long long bad_rows;
+    bool narrow;
+    Filter32 f32c;
+    bool fast_colour; /* the f32 stage of the colour filter applies to this render (wave-uniform, per launch) */
+    {
+        FR_COLD_PARAMS(kp);
+        const auto &P = *kp;
+        if (P.palette != nullptr) {
+            const uint32_t n = P.palette_entries;
+            const uint32_t *src = P.palette;
+            for (uint32_t k = lane; k < n; k += 64) s_palette[k] = src[k];
+            s_pal = s_palette;
+            __syncthreads();
+        }
+        row0 = (blockIdx.y + gridDim.y * blockIdx.z) * (8u * kBands);
+        nrows = P.nrows, ncols = P.ncols;
+        if (row0 >= nrows) return;
+        const double width = (double)P.width, height = (double)P.height;
+        tile0 = blockIdx.x * kStripTiles;
+        const uint32_t block_rows = P.block_rows;
+        const uint32_t x = P.x_first + (tile0 * 8u + lane) * P.x_stride;
+        const double cols = coord_to_space((double)x, height, (width / height) / 2.0, P.pos_re, P.scale_re);
+        const uint32_t rr = row0 + lane;
+        const uint32_t y = P.y_first + (rr / block_rows) * P.y_stride + rr % block_rows;
+        const double rows = coord_to_space((double)y, height, 0.5, P.pos_im, P.scale_im);
+        colsT = (T)cols, rowsT = (T)rows;
+        bpp = P.out_rgba ? 4u : 3u;
+        narrow = (uint64_t)ncols * bpp * 8u <= 0xFFFFFFFFull;
+        lane_pitch = ly * (ncols * bpp) + lx * bpp;
+        const bool is_julia = P.algo == 2;
+        bool c_ok = true;
+        if (is_julia) {
+            constexpr T lo = ScalableRange<T>::lo, hi = ScalableRange<T>::hi;
+            const T jr = __builtin_fabs((T)P.julia_re), ji = __builtin_fabs((T)P.julia_im);
+            c_ok = jr >= lo && jr <= hi && ji >= lo && ji <= hi;
+        }
+        const bool col_relevant = lane < 8u * kStripTiles && tile0 * 8u + lane < ncols;
+        const bool row_relevant = lane < 8u * kBands && rr < nrows;
+        cols_scalable = c_ok && __ballot(col_relevant && !coord_is_scalable<T>(is_julia, cols)) == 0ull;
+        bad_rows = __ballot(row_relevant && !coord_is_scalable<T>(is_julia, rows));
+        /* colour_multiply's RGB::new(r, b, g) swap (calc/src/lib.rs:129-139): output channel k takes field {0, 2, 1}[k] */
+        fast_colour = P.colour_filter32 && P.smooth && P.palette == nullptr;
+        f32c.lo = P.filt_lo32, f32c.k = P.filt_k32;
+        f32c.p0 = P.prim32[0], f32c.p1 = P.prim32[2], f32c.p2 = P.prim32[1];
+        f32c.d0 = P.filt_d32[0], f32c.d1 = P.filt_d32[2], f32c.d2 = P.filt_d32[1];
+    }
+    const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_keep; /* the host guarantees 0 < k1 < cap < 2^24 */
+    const bool julia = p.algo == 2;
+    const T jre = (T)p.julia_re, jim = (T)p.julia_im;
+    const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
+    const T skip_t = (T)p.skip_t;
+    const T t4v = (T)4 * skip_t, lim4v = (T)4 * squared;
+    const UB t4lim = uniform_bits<T>(t4v), lim4 = uniform_bits<T>(lim4v);
+    T c2re = jre + jre, c2im = jim + jim; /* Julia: c = julia_set (calc/src/lib.rs:209-210); Mandelbrot: set per tile */
+    /* the asm path runs a whole first episode and up to 64 exact iterations without looking at the cap */
+    const bool fast_tiles = k1 % (uint32_t)M == 0u && k1 + 64u <= cap;
+    const uint32_t nblk1 = k1 / (uint32_t)M;
+
+  for (int band = 0; band < kBands; band++) {
+    const uint32_t rb = row0 + 8u * (uint32_t)band;
+    if (rb >= nrows) break; /* wave-uniform */
+    const T sim = __shfl(rowsT, band * 8 + (int)ly, 64);
+    const T Y0 = sim + sim, B0 = Y0 * Y0;
+    const bool strip_scalable = cols_scalable && ((bad_rows >> (8 * band)) & 0xFFull) == 0ull;
+    const bool rows_full = rb + 8u <= nrows;
+    uint32_t out_row0 = rb;
+    {
+        FR_COLD_PARAMS(kp);
+        if (kp->out_in_place) out_row0 = kp->y_first + (rb / kp->block_rows) * kp->y_stride + rb % kp->block_rows;
+    }
+    const uint32_t r_out = out_row0 + ly;
+    uint8_t *const strip_base = out.rgb + ((uint64_t)out_row0 * ncols + (uint64_t)tile0 * 8u) * bpp;
+    const uint32_t r = rb + ly;
+    const uint32_t list = (blockIdx.x + 5u * (rb >> 3)) & (FR_SURV_QUEUES - 1u); /* neighbouring strips: different lists */
+    const bool fast_band = fast_tiles && strip_scalable && rows_full;
+
+    for (int k = 0; k < kStripTiles; k++) {
+        const uint32_t col0 = (tile0 + k) * 8u;
+        if (col0 >= ncols) break; /* wave-uniform */
+        const T sre = __shfl(colsT, k * 8 + (int)lx, 64);
+        const uint32_t cx = col0 + lx;
+        const bool full = rows_full && col0 + 8u <= ncols;
+        unsigned long long valid_m = ~0ull;
+        if (!full) valid_m = __ballot(cx < ncols && r < nrows);
+        /* where the tile's pixels go: a wave-uniform base and one 32-bit byte offset per lane */
+        uint8_t *o;
+        if (narrow) {
+            o = strip_base + (size_t)((uint32_t)k * 8u * bpp) + (size_t)lane_pitch;
+        } else {
+            o = out.rgb + ((uint64_t)r_out * ncols + cx) * bpp;
+        }
+        unsigned long long fin; /* the lanes whose pixel is coloured and stored here */
+        uint32_t packed = 0;    /* r | g << 8 | b << 16 */
+        bool have_colour = false;
+        if (strip_scalable) {
+            T X, Y, A, B, t;
+            float cnt;
+            unsigned long long run = 0ull, over0 = 0ull, esc = 0ull, live = 0ull;
+            uint32_t done = 0, st = 2;
+            if (!julia) c2re = sre + sre, c2im = Y0; /* Mandelbrot: c = start */
+            if (fast_band && full) {
+                st = tile_fast<T, M>(nblk1, sre, Y0, B0, c2re, c2im, t4lim, lim4, X, Y, A, B, t, cnt, run);
+                /* The common case to its end, apart from everything else (no state shared with the general path
+                 * below, so nothing is merged or copied for it): every lane escaped, and the filter's first stage
+                 * decides every lane's bytes from the f32 squared distance — (A + B) / 4 IS fl(re^2 + im^2), see
+                 * colour_pixel; f64 renders round it to f32 as the filter always did — with cnt = iters + 1. */
+                if (st == 0u && fast_colour) {
+                    const float d32 = (float)t * 0.25f;
+                    const bool unsure = !(d32 >= f32c.lo && d32 <= 0x1.ffffep119f);
+                    if (__ballot(unsure) == 0ull) {
+                        uint32_t pk;
+                        const bool decided = colour_fast32(f32c, d32, cnt, pk);
+                        if (__ballot(!decided) == 0ull) {
+                            if (bpp == 4u) {
+                                *reinterpret_cast<uint32_t *>(o) = pk | 0xFF000000u;
+                            } else {
+                                const uint16_t rg = (uint16_t)pk;
+                                __builtin_memcpy(o, &rg, 2); /* one (unaligned) 16-bit store and the high byte of the same register */
+                                o[2] = (uint8_t)(pk >> 16);
+                            }
+                            continue;
+                        }
+                    }
+                }
+            }
+            if (st == 0u) {
+                fin = esc = ~0ull;
+            } else {
+                /* ---- the general path; picks the tile up where the asm path left it */
+                if (st == 2u) {
+                    X = sre + sre, Y = Y0, A = X * X, B = B0, t = A + B, cnt = 0.0f;
+                    /* a start already past T never enters the unchecked blocks: it goes to the exact loop, from iteration 0 */
+                    over0 = __ballot(t > t4v) & valid_m;
+                    run = valid_m & ~over0;
+                }
+                unsigned long long handed = 0ull;
+                if (st != 3u) {
+                    /* episodes of k1 iterations for as long as the tile is worth a wave of its own — at least `keep`
+                     * lanes still running; a tile still here after 8 episodes is most likely inside a filled set: from
+                     * then on every episode is twice the last, up to 8 x k1 */
+                    uint32_t len = k1;
+                    bool first = st == 1u; /* the asm path has run the first episode */
+                    while (run != 0ull) {
+                        if (!first) {
+                            const uint32_t left = cap - done;
+                            const uint32_t nblk = (left < len ? left : len) / (uint32_t)M;
+                            if (nblk == 0u) break; /* fewer than M iterations to the cap: the exact loop below runs them */
+                            run = first_blocks<T, M>(run, nblk, X, Y, A, B, t, cnt, c2re, c2im, t4lim);
+                            done += nblk * (uint32_t)M;
+                        } else {
+                            done = k1;
+                            first = false;
+                        }
+                        if (run == 0ull || cap - done < (uint32_t)M) break;
+                        if ((uint32_t)__builtin_popcountll(run) < keep) break;
+                        if (done >= 8u * k1 && len < 8u * k1) len += len;
+                    }
+                    if (st == 1u && done == 0u) done = k1;
+                    /* hand the running lanes over: position after `done` iterations, recursive()'s own state */
+                    if (run != 0ull && cap - done >= (uint32_t)M) {
+                        FR_COLD_PARAMS(kp);
+                        const uint32_t sub_cap = kp->surv_sub_capacity;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(kp->surv_counts + list * FR_SURV_COUNT_STRIDE, (uint32_t)__builtin_popcountll(run));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
+                        const bool mine = lane_in(run) && slot < sub_cap; /* a full list is not an error: those lanes finish here */
+                        if (mine) {
+                            const size_t e = (size_t)list * sub_cap + slot;
+                            T2 zz;
+                            zz.x = X * (T)0.5, zz.y = Y * (T)0.5; /* exact */
+                            static_cast<T2 *>(kp->surv_z)[e] = zz;
+                            reinterpret_cast<uint2 *>(kp->surv_pos)[e] = make_uint2(cx, r_out);
+                            kp->surv_cnt[e] = done;
+                            if (!julia) {
+                                T2 cc2;
+                                cc2.x = sre, cc2.y = sim;
+                                static_cast<T2 *>(kp->surv_c)[e] = cc2;
+                            }
+                        }
+                        handed = __ballot(mine);
+                    }
+                    fin = valid_m & ~handed;
+                    if (fin == 0ull) continue; /* the whole tile went to the lists */
+                    /* `esc` = lanes whose last iteration escaped (their count - 1 is the index): tested AFTER an iteration
+                     * only, so not for a start past T; NaN: no */
+                    esc = __ballot(t > lim4v) & fin & ~over0;
+                    live = fin & ~esc;
+                } else {
+                    fin = ~0ull, live = run, esc = ~run, done = k1 + 64u;
+                }
+                /* the exact loop, once per tile, for every lane that is not done: the frozen ones (4-5 iterations from
+                 * limit^2), starts past T, the running lanes of a tile that reached the cap's last M - 1 iterations or
+                 * found its list full */
+                uint32_t bound = done; /* no lane's count exceeds it */
+                while (live != 0ull) {
+                    uint32_t nf = 64u;
+                    if (bound + 64u > cap) {
+                        /* near the cap the lanes' room differs: the largest count decides, lanes at the cap retire */
+                        live &= ~__ballot((uint32_t)cnt >= cap);
+                        if (live == 0ull) break;
+                        nf = cap - wave_max_u32(lane_in(live) ? (uint32_t)cnt : 0u);
+                        bound = cap - nf;
+                    }
+                    const unsigned long long still = finish_scaled<T>(live, nf, X, Y, A, B, t, cnt, c2re, c2im, lim4);
+                    esc |= live & ~still;
+                    live = still;
+                    bound += nf;
+                }
+            }
+            /* ---- colour (calc/src/lib.rs:214-234).  The filter's first stage from the f32 squared distance (see
+             * colour_pixel): (A + B) / 4 IS fl(re^2 + im^2) — f64 renders round it to f32 as the filter always did —
+             * and cnt = iters + 1 for an escaped lane */
+            if (fast_colour && esc == fin) { /* wave-uniform */
+                const float d32 = (float)t * 0.25f;
+                const bool unsure = !(d32 >= f32c.lo && d32 <= 0x1.ffffep119f);
+                if ((__ballot(unsure) & fin) == 0ull) {
+                    const bool decided = colour_fast32(f32c, d32, cnt, packed);
+                    have_colour = (__ballot(!decided) & fin) == 0ull;
+                }
+            }
+            if (!have_colour) {
+                const T re = X * (T)0.5, im = Y * (T)0.5; /* exact */
+                const T r2 = re * re, i2 = im * im;       /* the reference's own re*re, im*im */
+                const uint32_t iters = lane_in(esc) ? (uint32_t)cnt - 1u : cap;
+                if (lane_in(fin)) {
+                    FR_COLD_PARAMS(kp);
+                    const ColourConsts cc = make_colour_consts(*kp);
+                    uint8_t rgb[3];
+                    colour_pixel<T>(cc, re, im, r2, i2, iters, s_tab, s_pal, rgb);
+                    packed = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16);
+                }
+            }
+        } else {
+            /* a strip that may not use the scaled form: the plain loop from the start, the general colour path */
+            fin = valid_m;
+            T re = sre, im = sim, r2 = 0, i2 = 0;
+            const T cre = julia ? jre : re, cim = julia ? jim : im;
+            if (lane_in(valid_m)) {
+                const uint32_t iters = orbit<T>(cap, re, im, cre, cim, squared, r2, i2);
+                FR_COLD_PARAMS(kp);
+                const ColourConsts cc = make_colour_consts(*kp);
+                uint8_t rgb[3];
+                colour_pixel<T>(cc, re, im, r2, i2, iters, s_tab, s_pal, rgb);
+                packed = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16);
+            }
+        }
+        /* ---- store (src/lib.rs:253-270) */
+        if (fin == ~0ull || lane_in(fin)) {
+            if (bpp == 4u) {
+                *reinterpret_cast<uint32_t *>(o) = packed | 0xFF000000u;
+            } else {
+                const uint16_t rg = (uint16_t)packed;
+                __builtin_memcpy(o, &rg, 2); /* one (unaligned) 16-bit store and the high byte of the same register */
+                o[2] = (uint8_t)(packed >> 16);
             }
         }
     }
@@ -1410,14 +1920,6 @@ hipError_t launch_refill(const fr_kparams &p, int mode, const fr_kout &out, hipS
  * of patches or where the main loop hands it over. */
 constexpr uint32_t kQPatchW = 64, kQPatchH = 32;
 constexpr uint32_t kQStack = 128;
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
 
 /* One run of the main loop: blocks of M unchecked scaled iterations, one |z|^2 <= T test per block.
  * In: the active lanes (EXEC) all have A + B <= 4T.  Out: `running` = the lanes that passed every test
@@ -1948,7 +2450,7 @@ hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t str
 /* Two passes, RGB output only; needs the survivor lists and p.work_counter (all counters zeroed on the launch
  * stream by the caller) and 0 < p.first_cap < p.iterations */
 template <typename T>
-hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
+hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream, bool v1 = false) {
     if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
     constexpr int kStripTiles = 7;
     const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
@@ -1963,7 +2465,28 @@ hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t 
     const uint64_t gz = (row_blocks + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
-    if (p.loop_mode == 4 && bands == 4)
+    /* tuning aid: FR_DEBUG_FIRST_LDS = bytes of (unused) dynamic LDS per workgroup, to study the first pass at a
+     * lower occupancy (160 KB per CU: 40960 -> 1 wave per SIMD, 20480 -> 2, 10240 -> 4, ...) */
+    static const size_t dbg_lds = [] {
+        const char *e = getenv("FR_DEBUG_FIRST_LDS");
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    static const int dbg_bands = [] {
+        const char *e = getenv("FR_DEBUG_FIRST_BANDS");
+        return e ? atoi(e) : 0;
+    }();
+    if (dbg_bands == 8 && p.loop_mode == 4 && bands == 4 && !v1) {
+        const uint64_t rb8 = (row_tiles + 7) / 8;
+        const uint64_t gy8 = rb8 < 32768 ? rb8 : 32768;
+        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 8>), dim3((uint32_t)gx, (uint32_t)gy8, (uint32_t)((rb8 + gy8 - 1) / gy8)), dim3(64), dbg_lds, stream, p, out);
+    } else if (dbg_lds && p.loop_mode == 4 && bands == 4 && !v1) {
+        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), dbg_lds, stream, p, out);
+    } else
+    if (v1 && p.loop_mode == 4 && bands == 4) /* round 2's first pass, kept for comparison (tile 12) */
+        hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
+    else if (v1 && p.loop_mode == 4)
+        hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+    else if (p.loop_mode == 4 && bands == 4)
         hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
     else if (p.loop_mode == 4)
         hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
@@ -2028,7 +2551,7 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 template <typename T>
 hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream,
                             const char *&name) {
-    if (p.out_in_place && tile > 11) tile = 0; /* only the strip kernels know in-place addressing */
+    if (p.out_in_place && tile > 12) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
         name = FR_KNAME("escape_kernel", "64x1");
@@ -2077,6 +2600,12 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
     case 8:
         name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
+    case 12: /* two passes with round 2's first pass (comparison only) */
+        if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
+            name = FR_KNAME("escape_first_v1_kernel + escape_queue_kernel", "round 2's first pass, then persistent waves over the survivor lists");
+            return launch_two_pass<T>(p, out, stream, true);
+        }
+        [[fallthrough]];
     case 11: /* two passes: strips to first_cap, then the work-queue kernel over the survivors (otherwise as 9) */
         if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
             name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
@@ -2242,7 +2771,7 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile) {
          * 131 072 tiles 0.17 / 0.22 against 0.20 / 0.33; at 32 768 tiles and below the strips win in f32 */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
         if (p.algo != 2 || tiles < 65536) return false;
-    } else if (tile != 11) {
+    } else if (tile != 11 && tile != 12) {
         return false;
     }
     /* first_cap: a multiple of the loop's block length; the second pass must have something left to do */

@@ -40,6 +40,7 @@ namespace {
 
 constexpr uint32_t kDefaultBlockRows = 256;
 constexpr uint32_t kMaxChunkBlocks = 8;
+constexpr const char *kEchoError = "another device of the set failed";
 
 double now_ms() {
     using namespace std::chrono;
@@ -354,7 +355,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
      * flight on three streams into memory the caller frees when we return): no `return` in here. */
     for (size_t c = 0; c < chunks.size() && rc == FR_OK; c++) {
         if (j.abort->load(std::memory_order_acquire)) {
-            rc = fail(FR_ERR_HIP, "another device of the set failed");
+            rc = fail(FR_ERR_HIP, kEchoError);
             break;
         }
         if (g_inject_device.load() == (int)r && g_inject_chunk.load() == (int)c) {
@@ -447,7 +448,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
                 /* the pinner makes the buffer DMA-able front to back while we render: wait for this block's bytes */
                 if (!plain_copies && !j.pins->wait_for(dst_off, dst_off + bytes, *j.abort)) plain_copies = true;
                 if (j.abort->load(std::memory_order_acquire)) {
-                    rc = fail(FR_ERR_HIP, "another device of the set failed");
+                    rc = fail(FR_ERR_HIP, kEchoError);
                     break;
                 }
                 if (plain_copies) {
@@ -545,12 +546,17 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
         Worker *wp = w.get();
         wp->post([wp, &job, &stats] { return device_job(*wp, job, &stats); });
     }
+    /* report the failure that started it, not the "another device of the set failed" of those that stopped for it */
     std::string first_err;
+    bool have_cause = false;
     for (auto &w : set->workers) {
         const int r = w->wait();
-        if (r != FR_OK && rc == FR_OK) {
+        if (r == FR_OK) continue;
+        const bool echo = w->err.rfind(kEchoError, 0) == 0;
+        if (rc == FR_OK || (!have_cause && !echo)) {
             rc = r;
             first_err = "device " + std::to_string(w->index) + ": " + w->err;
+            have_cause = !echo;
         }
     }
     if (pins) pins->finish(); /* every device has drained its streams */

@@ -182,3 +182,24 @@ def test_soft_log2_tracks_libm():
         assert O.log2(x) == want
     assert math.isnan(O.log2(-1.0)) and math.isnan(O.log2(math.nan))
     O.set_log2_mode(O.LOG2_LIBM)
+
+
+def test_oracle_soft_log2_is_a_verbatim_copy():
+    """The oracle builds from oracle/ alone (VERDICT r02 weak #1b): its soft-mode log2 is a COPY of the product's
+    fr_math.h + table.  The copy must not drift: the table byte for byte, the header from its original first
+    line on."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = os.path.join(root, "fractal-renderer_amd", "csrc")
+    with open(os.path.join(root, "oracle", "fr_log2_table.inc"), "rb") as a, open(os.path.join(prod, "fr_log2_table.inc"), "rb") as b:
+        assert a.read() == b.read()
+    copy = open(os.path.join(root, "oracle", "soft_log2.h")).read()
+    orig = open(os.path.join(prod, "fr_math.h")).read()
+    marker = " * fr_math.h — arithmetic shared by host and device code of the colour-mapping pass."
+    assert marker in copy and marker in orig
+    assert copy[copy.index(marker):] == orig[orig.index(marker):]
+    mk = open(os.path.join(root, "oracle", "Makefile")).read()
+    assert "fractal-renderer_amd" not in mk.replace("# ", ""), "oracle/Makefile must not reach into the product tree"
+    src = open(os.path.join(root, "oracle", "fractal_oracle.c")).read()
+    assert '#include "../' not in src
