@@ -1285,18 +1285,34 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
  *   1  lanes still run after the first episode (`srun`): further episodes or a hand-over
  *   2  nothing was done: some start lies beyond T
  *   3  64 exact iterations did not finish everybody (`srun` = the lanes still live) */
-#define FR_TILE_ASM(SFX, MOVT, BLOCK_ITS, STEP)        \
+#define FR_SC_IT0(SFX)                             \
+    "v_add_" SFX " %[t], %[A], -%[B0]\n"           \
+    "v_mul_" SFX " %[q], %[X], %[Y0]\n"            \
+    "v_fma_" SFX " %[X], %[t], 0.5, %[c2re]\n"     \
+    "v_add_" SFX " %[Y], %[q], %[c2im]\n"          \
+    "v_mul_" SFX " %[A], %[X], %[X]\n"             \
+    "v_mul_" SFX " %[B], %[Y], %[Y]\n"
+/* REST_ITS = the block's iterations after its first; the first block's first iteration reads Y0 / B0 where they
+ * lie (no copies) and its count is set, not added */
+#define FR_TILE_ASM(SFX, REST_ITS, STEP)               \
+    "s_load_dwordx2 %[fa], %[kargs], %[offa]\n"        \
+    "s_load_dwordx2 %[fb], %[kargs], %[offb]\n"        \
+    "s_load_dword %[fk], %[kargs], %[offk]\n"          \
     "v_add_" SFX " %[X], %[sre], %[sre]\n"             \
-    MOVT " %[Y], %[Y0]\n"                              \
     "v_mul_" SFX " %[A], %[X], %[X]\n"                 \
-    MOVT " %[B], %[B0]\n"                              \
-    "v_mov_b32 %[cnt], 0\n"                            \
-    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_" SFX " %[t], %[A], %[B0]\n"                \
     "s_mov_b32 %[st], 2\n"                             \
     "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"           \
     "s_cbranch_vccnz .Ltout_%=\n"                      \
     "s_mov_b64 %[sorig], exec\n"                       \
-    ".Ltb_%=:\n" BLOCK_ITS                             \
+    FR_SC_IT0(SFX) REST_ITS                            \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_mov_b32 %[cnt], " STEP "\n"                     \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_cbranch_execz .Ltbd_%=\n"                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc1 .Ltbd_%=\n"                        \
+    ".Ltb_%=:\n" FR_SC_IT(SFX) REST_ITS                \
     "v_add_" SFX " %[t], %[A], %[B]\n"                 \
     "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
     "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
@@ -1324,38 +1340,48 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
     ".Ltfd_%=:\n"                                      \
     "s_mov_b64 %[srun], exec\n"                        \
     "s_mov_b64 exec, %[sorig]\n"                       \
-    ".Ltout_%=:\n"
+    ".Ltout_%=:\n"                                     \
+    "s_waitcnt lgkmcnt(0)\n"
 
+/* Also fetches the colour filter's scalars for the caller — prim32[0..1], prim32[2] and filt_lo32, filt_k32 —
+ * from the kernel-argument segment: issued before the loops, waited for behind them, so that they cost neither
+ * resident scalar registers (they were spilled to vector lanes: 16 v_readlane per tile) nor exposed latency. */
 template <typename T, int M>
 __device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, T c2re, T c2im, typename UBits<T>::type t4lim,
-                                              typename UBits<T>::type lim4, T &X, T &Y, T &A, T &B, T &t, float &cnt,
-                                              unsigned long long &srun) {
+                                              typename UBits<T>::type lim4, KArgs kargs, T &X, T &Y, T &A, T &B, T &t, float &cnt,
+                                              unsigned long long &srun, unsigned long long &fa, unsigned long long &fb, uint32_t &fk) {
+    static_assert(offsetof(fr_kparams, filt_lo32) == offsetof(fr_kparams, prim32) + 12 && offsetof(fr_kparams, prim32) % 4 == 0,
+                  "prim32[0..1] | prim32[2], filt_lo32: two 8-byte loads");
     T q;
     unsigned long long sorig;
     uint32_t st, k = nblk - 1u;
 #define FR_TILE_OPERANDS                                                                                         \
     : [X] "=&v"(X), [Y] "=&v"(Y), [A] "=&v"(A), [B] "=&v"(B), [t] "=&v"(t), [cnt] "=&v"(cnt), [q] "=&v"(q),      \
-      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(k), [st] "=&s"(st)                                      \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(k), [st] "=&s"(st), [fa] "=&s"(fa), [fb] "=&s"(fb),     \
+      [fk] "=&s"(fk)                                                                                             \
     : [sre] "v"(sre), [Y0] "v"(Y0), [B0] "v"(B0), [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim),        \
-      [lim4] "s"(lim4)                                                                                           \
-    : "vcc", "scc"
+      [lim4] "s"(lim4), [kargs] "s"(kargs), [offa] "i"(offsetof(fr_kparams, prim32)),                            \
+      [offb] "i"(offsetof(fr_kparams, prim32) + 8),                                                              \
+      [offk] "i"(offsetof(fr_kparams, filt_k32))                                                                 \
+    : "vcc", "scc", "memory"
     if constexpr (sizeof(T) == 8) {
         if constexpr (M == 4)
-            asm volatile(FR_TILE_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_TILE_OPERANDS);
         else
-            asm volatile(FR_TILE_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64"), "2.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f64", FR_SC_IT("f64"), "2.0") FR_TILE_OPERANDS);
     } else {
         if constexpr (M == 4)
-            asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_TILE_OPERANDS);
         else
-            asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f32", FR_SC_IT("f32"), "2.0") FR_TILE_OPERANDS);
     }
     return st;
 }
 
 /* the filter's first stage with its constants held by the caller (scalar registers, loaded once per workgroup) */
 struct Filter32 {
-    float lo, k, p0, p1, p2, d0, d1, d2; /* channels in OUTPUT order (color_multiply's swap applied by the host side of this struct) */
+    float lo, k, p0, p1, p2; /* scalars; channels in OUTPUT order (color_multiply's swap applied where this is filled) */
+    float d0, d1, d2;        /* held per lane: a VOP3 takes ONE scalar operand, and the fma's 2^-21 is one already */
 };
 __device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, float itp1, uint32_t &lo) {
     const float l1 = __builtin_amdgcn_logf(d32);
@@ -1368,6 +1394,31 @@ __device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, floa
     lo = sat_u8_pack<2>(v2 - w2, sat_u8_pack<1>(v1 - w1, sat_u8_pack<0>(v0 - w0, 0u)));
     const uint32_t hi = sat_u8_pack<2>(v2 + w2, sat_u8_pack<1>(v1 + w1, sat_u8_pack<0>(v0 + w0, 0u)));
     return lo == hi;
+}
+
+/* one pixel per lane to `base + off` (a wave-uniform base in scalar registers, a 32-bit byte offset per lane: no
+ * vector address arithmetic): r,g,b as one 16-bit store — unaligned, as the compiler itself emits them on this
+ * target — plus the high byte of the same register, or r,g,b,255 as one dword */
+__device__ __forceinline__ void store_packed(uint8_t *base, uint32_t off, uint32_t packed, uint32_t bpp) {
+    if (bpp == 4u) {
+        const uint32_t v = packed | 0xFF000000u;
+        asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+    } else {
+        asm volatile("global_store_short %0, %1, %2\n\tglobal_store_byte_d16_hi %0, %1, %2 offset:2" : : "v"(off), "v"(packed), "s"(base) : "memory");
+    }
+}
+
+/* ds_bpermute of a T (lane `byte_index / 4`'s value), the index a ready-made byte offset */
+template <typename T>
+__device__ __forceinline__ typename UBits<T>::type bpermute_t(uint32_t byte_index, T v) {
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t b = fr_bits_of(v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_index, (int)(uint32_t)b);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_index, (int)(uint32_t)(b >> 32));
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    } else {
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_index, __builtin_bit_cast(int, v));
+    }
 }
 
 template <typename T, int M, int kStripTiles, int kBands>
@@ -1385,7 +1436,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     bool cols_scalable;
     unsigned long long bad_rows;
     bool narrow;
-    Filter32 f32c;
+    float fd0, fd1, fd2; /* the filter's three half-widths in output-channel order, one copy per lane (see Filter32) */
     bool fast_colour; /* the f32 stage of the colour filter applies to this render (wave-uniform, per launch) */
     {
         FR_COLD_PARAMS(kp);
@@ -1425,9 +1476,8 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         bad_rows = __ballot(row_relevant && !coord_is_scalable<T>(is_julia, rows));
         /* colour_multiply's RGB::new(r, b, g) swap (calc/src/lib.rs:129-139): output channel k takes field {0, 2, 1}[k] */
         fast_colour = P.colour_filter32 && P.smooth && P.palette == nullptr;
-        f32c.lo = P.filt_lo32, f32c.k = P.filt_k32;
-        f32c.p0 = P.prim32[0], f32c.p1 = P.prim32[2], f32c.p2 = P.prim32[1];
-        f32c.d0 = P.filt_d32[0], f32c.d1 = P.filt_d32[2], f32c.d2 = P.filt_d32[1];
+        fd0 = P.filt_d32[0], fd1 = P.filt_d32[2], fd2 = P.filt_d32[1];
+        asm volatile("" : "+v"(fd0), "+v"(fd1), "+v"(fd2)); /* vector registers from here on */
     }
     const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_keep; /* the host guarantees 0 < k1 < cap < 2^24 */
     const bool julia = p.algo == 2;
@@ -1440,6 +1490,11 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     /* the asm path runs a whole first episode and up to 64 exact iterations without looking at the cap */
     const bool fast_tiles = k1 % (uint32_t)M == 0u && k1 + 64u <= cap;
     const uint32_t nblk1 = k1 / (uint32_t)M;
+    /* the strip's tiles: `ntiles` lie (partly) inside the image, the first `nfull` of them with all 8 columns */
+    const uint32_t cols_left = ncols - tile0 * 8u; /* > 0: the grid has no workgroup past the right edge */
+    const uint32_t ntiles = (cols_left + 7u) / 8u < (uint32_t)kStripTiles ? (cols_left + 7u) / 8u : (uint32_t)kStripTiles;
+    const uint32_t nfull = cols_left / 8u < (uint32_t)kStripTiles ? cols_left / 8u : (uint32_t)kStripTiles;
+    const uint32_t lane_x4 = lx * 4u; /* ds_bpermute index of this lane's column within tile 0 of the strip */
 
   for (int band = 0; band < kBands; band++) {
     const uint32_t rb = row0 + 8u * (uint32_t)band;
@@ -1457,23 +1512,18 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     uint8_t *const strip_base = out.rgb + ((uint64_t)out_row0 * ncols + (uint64_t)tile0 * 8u) * bpp;
     const uint32_t r = rb + ly;
     const uint32_t list = (blockIdx.x + 5u * (rb >> 3)) & (FR_SURV_QUEUES - 1u); /* neighbouring strips: different lists */
-    const bool fast_band = fast_tiles && strip_scalable && rows_full;
+    /* tiles [0, nfast) of this strip may try the asm path */
+    const uint32_t nfast = (fast_tiles && strip_scalable && rows_full && narrow) ? nfull : 0u;
 
-    for (int k = 0; k < kStripTiles; k++) {
+    for (uint32_t k = 0; k < ntiles; k++) {
         const uint32_t col0 = (tile0 + k) * 8u;
-        if (col0 >= ncols) break; /* wave-uniform */
-        const T sre = __shfl(colsT, k * 8 + (int)lx, 64);
+        const T sre = __builtin_bit_cast(T, bpermute_t<T>(lane_x4 + k * 32u, colsT));
         const uint32_t cx = col0 + lx;
-        const bool full = rows_full && col0 + 8u <= ncols;
+        const bool full = rows_full && k < nfull;
         unsigned long long valid_m = ~0ull;
         if (!full) valid_m = __ballot(cx < ncols && r < nrows);
-        /* where the tile's pixels go: a wave-uniform base and one 32-bit byte offset per lane */
-        uint8_t *o;
-        if (narrow) {
-            o = strip_base + (size_t)((uint32_t)k * 8u * bpp) + (size_t)lane_pitch;
-        } else {
-            o = out.rgb + ((uint64_t)r_out * ncols + cx) * bpp;
-        }
+        /* where the tile's pixels go: a wave-uniform base and one 32-bit byte offset per lane (narrow images) */
+        uint8_t *const tile_base = strip_base + (size_t)(k * 8u * bpp);
         unsigned long long fin; /* the lanes whose pixel is coloured and stored here */
         uint32_t packed = 0;    /* r | g << 8 | b << 16 */
         bool have_colour = false;
@@ -1483,26 +1533,33 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
             unsigned long long run = 0ull, over0 = 0ull, esc = 0ull, live = 0ull;
             uint32_t done = 0, st = 2;
             if (!julia) c2re = sre + sre, c2im = Y0; /* Mandelbrot: c = start */
-            if (fast_band && full) {
-                st = tile_fast<T, M>(nblk1, sre, Y0, B0, c2re, c2im, t4lim, lim4, X, Y, A, B, t, cnt, run);
+            if (k < nfast) {
+                /* the filter's scalars: re-read from the kernel-argument segment HERE, before the orbit loop that hides
+                 * the loads' latency, instead of being held in scalar registers across the workgroup (they were
+                 * spilled to vector lanes and every tile paid 16 v_readlane — vector-issue slots — to get them back):
+                 * tile_fast issues the two loads before its loops and waits for them behind them */
+                unsigned long long fa, fb;
+                uint32_t fk;
+                st = tile_fast<T, M>(nblk1, sre, Y0, B0, c2re, c2im, t4lim, lim4, (KArgs)__builtin_amdgcn_kernarg_segment_ptr(), X, Y, A,
+                                     B, t, cnt, run, fa, fb, fk);
+                Filter32 fc;
+                fc.lo = __builtin_bit_cast(float, (uint32_t)(fb >> 32)), fc.k = __builtin_bit_cast(float, fk);
+                /* colour_multiply's RGB::new(r, b, g) swap: output channel k takes stored field {0, 2, 1}[k] */
+                fc.p0 = __builtin_bit_cast(float, (uint32_t)fa), fc.p1 = __builtin_bit_cast(float, (uint32_t)fb);
+                fc.p2 = __builtin_bit_cast(float, (uint32_t)(fa >> 32));
+                fc.d0 = fd0, fc.d1 = fd1, fc.d2 = fd2;
                 /* The common case to its end, apart from everything else (no state shared with the general path
                  * below, so nothing is merged or copied for it): every lane escaped, and the filter's first stage
                  * decides every lane's bytes from the f32 squared distance — (A + B) / 4 IS fl(re^2 + im^2), see
                  * colour_pixel; f64 renders round it to f32 as the filter always did — with cnt = iters + 1. */
                 if (st == 0u && fast_colour) {
                     const float d32 = (float)t * 0.25f;
-                    const bool unsure = !(d32 >= f32c.lo && d32 <= 0x1.ffffep119f);
+                    const bool unsure = !(d32 >= fc.lo && d32 <= 0x1.ffffep119f);
                     if (__ballot(unsure) == 0ull) {
                         uint32_t pk;
-                        const bool decided = colour_fast32(f32c, d32, cnt, pk);
+                        const bool decided = colour_fast32(fc, d32, cnt, pk);
                         if (__ballot(!decided) == 0ull) {
-                            if (bpp == 4u) {
-                                *reinterpret_cast<uint32_t *>(o) = pk | 0xFF000000u;
-                            } else {
-                                const uint16_t rg = (uint16_t)pk;
-                                __builtin_memcpy(o, &rg, 2); /* one (unaligned) 16-bit store and the high byte of the same register */
-                                o[2] = (uint8_t)(pk >> 16);
-                            }
+                            store_packed(tile_base, lane_pitch, pk, bpp);
                             continue;
                         }
                     }
@@ -1598,6 +1655,13 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
              * and cnt = iters + 1 for an escaped lane */
             if (fast_colour && esc == fin) { /* wave-uniform */
                 const float d32 = (float)t * 0.25f;
+                Filter32 f32c;
+                {
+                    FR_COLD_PARAMS(kp);
+                    f32c.lo = kp->filt_lo32, f32c.k = kp->filt_k32;
+                    f32c.p0 = kp->prim32[0], f32c.p1 = kp->prim32[2], f32c.p2 = kp->prim32[1];
+                    f32c.d0 = fd0, f32c.d1 = fd1, f32c.d2 = fd2;
+                }
                 const bool unsure = !(d32 >= f32c.lo && d32 <= 0x1.ffffep119f);
                 if ((__ballot(unsure) & fin) == 0ull) {
                     const bool decided = colour_fast32(f32c, d32, cnt, packed);
@@ -1632,12 +1696,15 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         }
         /* ---- store (src/lib.rs:253-270) */
         if (fin == ~0ull || lane_in(fin)) {
-            if (bpp == 4u) {
-                *reinterpret_cast<uint32_t *>(o) = packed | 0xFF000000u;
+            if (narrow) {
+                store_packed(tile_base, lane_pitch, packed, bpp);
             } else {
-                const uint16_t rg = (uint16_t)packed;
-                __builtin_memcpy(o, &rg, 2); /* one (unaligned) 16-bit store and the high byte of the same register */
-                o[2] = (uint8_t)(packed >> 16);
+                uint8_t *o = out.rgb + ((uint64_t)r_out * ncols + cx) * bpp;
+                if (bpp == 4u) {
+                    *reinterpret_cast<uint32_t *>(o) = packed | 0xFF000000u;
+                } else {
+                    o[0] = (uint8_t)packed, o[1] = (uint8_t)(packed >> 8), o[2] = (uint8_t)(packed >> 16);
+                }
             }
         }
     }
