@@ -395,6 +395,14 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     p.first_keep = ((o.tile == 11 || o.tile == 12) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
     p.two_pass_cap = ((o.tile == 11 || o.tile == 12) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
     p.queue_want = (o.refill_quit16 < 0 || o.tile == 11 || o.tile == 12) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
+    {
+        /* tuning aid: the second pass's own policy under the two-pass render (whose fr_set_refill_policy numbers
+         * steer the first pass): FR_DEBUG_QUEUE_WANT / FR_DEBUG_QUEUE_MINRUN */
+        static const int dbg_want = getenv("FR_DEBUG_QUEUE_WANT") ? atoi(getenv("FR_DEBUG_QUEUE_WANT")) : 0;
+        static const int dbg_minrun = getenv("FR_DEBUG_QUEUE_MINRUN") ? atoi(getenv("FR_DEBUG_QUEUE_MINRUN")) : -1;
+        if (dbg_want > 0 && dbg_want <= 64) p.queue_want = (uint32_t)dbg_want;
+        if (dbg_minrun >= 0) p.queue_minrun = (uint32_t)dbg_minrun;
+    }
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
     /* the colour filter's constants (fr_kernels.hip: colour_outside_filtered) and the conditions under

@@ -2542,7 +2542,15 @@ hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t 
         const char *e = getenv("FR_DEBUG_FIRST_BANDS");
         return e ? atoi(e) : 0;
     }();
-    if (dbg_bands == 8 && p.loop_mode == 4 && bands == 4 && !v1) {
+    if ((dbg_bands == 2 || dbg_bands == 1) && p.loop_mode == 4 && bands == 4 && !v1) {
+        const uint64_t rbk = (row_tiles + dbg_bands - 1) / dbg_bands;
+        const uint64_t gyk = rbk < 32768 ? rbk : 32768;
+        const dim3 gk((uint32_t)gx, (uint32_t)gyk, (uint32_t)((rbk + gyk - 1) / gyk));
+        if (dbg_bands == 2)
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 2>), gk, dim3(64), dbg_lds, stream, p, out);
+        else
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), gk, dim3(64), dbg_lds, stream, p, out);
+    } else if (dbg_bands == 8 && p.loop_mode == 4 && bands == 4 && !v1) {
         const uint64_t rb8 = (row_tiles + 7) / 8;
         const uint64_t gy8 = rb8 < 32768 ? rb8 : 32768;
         hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 8>), dim3((uint32_t)gx, (uint32_t)gy8, (uint32_t)((rb8 + gy8 - 1) / gy8)), dim3(64), dbg_lds, stream, p, out);

@@ -474,7 +474,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     if (rc != FR_OK) {
         /* tell the others, and — RCCL — release the peers that wait for transfers this device will never post */
         j.abort->store(true, std::memory_order_release);
-        j.pins->wake();
+        if (j.pins) j.pins->wake();
         if (j.sink == Sink::Rccl) rc_lib.abort_all();
     }
     /* drain, error or not */

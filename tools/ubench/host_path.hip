@@ -141,6 +141,32 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // 1d. the same for memory the CALLER touched without a huge-page hint (4-KiB pages unless THP is "always"):
+    //     what a buffer that already exists costs to pin, by thread count (64 MiB chunks)
+    for (int T : {1, 2, 4, 8}) {
+        uint8_t *h = fresh(N);
+        par(8, N, [&](size_t a, size_t b) { memset(h + a, 1, b - a); });
+        const size_t band = (size_t)64 << 20, nb = (N + band - 1) / band;
+        std::atomic<size_t> next{0};
+        double t0 = now_ms();
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&] {
+                    for (;;) {
+                        const size_t b = next.fetch_add(1);
+                        if (b >= nb) break;
+                        const size_t a = b * band;
+                        (void)hipHostRegister(h + a, a + band < N ? band : N - a, hipHostRegisterPortable);
+                    }
+                });
+            for (auto &t : th) t.join();
+        }
+        double t1 = now_ms();
+        for (size_t a = 0; a < N; a += band) (void)hipHostUnregister(h + a);
+        printf("register resident 4-KiB-page memory, 64 MiB chunks, %d thread(s): %.2f ms (%.1f GB/s)\n", T, t1 - t0, N / (t1 - t0) / 1e6);
+        munmap(h, N);
+    }
     if (argc > 2 && !strcmp(argv[2], "regonly")) return 0;
     // 2. first touch by T threads
     for (int T : {1, 2, 4, 8, 16}) {
