@@ -81,6 +81,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every core this process may use")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the measured run of a plain --gpus N (see supervise)
+    ap.add_argument("--child-timeout", type=float, default=float(os.environ.get("FR_BENCH_CHILD_TIMEOUT", "900")),
+                    help="plain --gpus N: seconds a measured child process may take before it is killed and the peer-DMA "
+                         "gather is tried in a fresh one")
     return ap.parse_args()
 
 
@@ -597,6 +601,61 @@ def run_distributed(args, torch, fr, lib, native, world, rank, local_rank):
     dist.destroy_process_group()
 
 
+def supervise(args):
+    """Plain `python3 bench.py --gpus N` (N > 1, no launcher).  This process makes NO GPU call (it never imports
+    torch): the measured run is a fresh CHILD process with a time limit.  The first real N > 1 run is also the first
+    test of the in-library RCCL gather on more than one GPU (VERDICT r02 #2b), so: if the child hangs (killed with its
+    whole process group at the limit) or exits non-zero, a second fresh child runs the same workload with the
+    peer-to-peer DMA gather; if that fails too, a JSON line with an "error" field is printed and the exit code is 1.
+    A process that has touched the GPU is never re-executed."""
+    import signal
+    import subprocess
+
+    base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--child"] + ["--child"]
+
+    def run(extra):
+        p = subprocess.Popen(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=args.child_timeout)
+            return p.returncode, out, err, False
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)  # the child and whatever it started
+            except ProcessLookupError:
+                pass
+            out, err = p.communicate()
+            return -9, out, err, True
+
+    def last_json(out):
+        for ln in reversed(out.splitlines()):
+            if ln.startswith("{"):
+                try:
+                    return json.loads(ln)
+                except ValueError:
+                    pass
+        return None
+
+    attempts = []
+    for extra, what in (([], "gather as requested (--gather %s)" % args.gather), (["--gather", "peer"], "peer-to-peer DMA gather")):
+        if attempts and args.gather == "peer":
+            break  # the request WAS the peer gather: nothing else to fall back on
+        rc, out, err, timed_out = run(extra)
+        d = last_json(out)
+        attempts.append({"what": what, "exit_code": rc, "timed_out": timed_out,
+                         "stderr_tail": err[-600:] if rc != 0 else ""})
+        if rc == 0 and d is not None:
+            if len(attempts) > 1:
+                d["fallback"] = {"reason": "the first child %s" % ("hung and was killed after %.0f s" % args.child_timeout
+                                                                     if attempts[0]["timed_out"] else
+                                                                     "exited with code %d" % attempts[0]["exit_code"]),
+                                 "attempts": attempts}
+            print(json.dumps(d), flush=True)
+            return 0
+    print(json.dumps({"metric": "pixel_iterations_per_sec", "value": None, "unit": "pixel-iterations/s", "n_gpus": args.gpus,
+                      "error": "every measured child process failed", "attempts": attempts}), flush=True)
+    return 1
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -605,6 +664,10 @@ def main():
     # FR_BENCH_DISTRIBUTED=1: take the one-process-per-GPU path even at world size 1 (a one-GPU box then exercises
     # its process-group set-up, collectives and bookkeeping; tests/test_gpu_multi.py)
     launched = "RANK" in os.environ and (world > 1 or os.environ.get("FR_BENCH_DISTRIBUTED") == "1")
+    if args.gpus > 1 and not launched and not args.child:
+        sys.exit(supervise(args))
+    if args.child and os.environ.get("FR_BENCH_TEST_STALL") == args.gather:
+        time.sleep(1e6)  # test hook: a child that never comes back (tests/test_abi_cpu.py kills it through the supervisor)
 
     import torch  # first: the library then shares torch's HIP runtime
 

@@ -136,6 +136,8 @@ PROTOTYPES = {
     "fr_multi_last_stats": (C.c_int, [C.POINTER(fr_multi_stats)]),
     "fr_debug_rccl_selftest": (C.c_int, [C.c_size_t]),
     "fr_debug_rccl_probe": (C.c_int, []),
+    "fr_set_dispatch_sampling": (C.c_int, [C.c_int]),
+    "fr_debug_sample_view": (C.c_int, [C.POINTER(fr_config), C.c_int, C.POINTER(C.c_double)]),
     "fr_debug_inject_multi_failure": (C.c_int, [C.c_int, C.c_int]),
     "fr_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
     "fr_unpin_host_buffer": (C.c_int, [C.c_void_p]),

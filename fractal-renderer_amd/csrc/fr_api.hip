@@ -55,7 +55,7 @@ std::atomic<uint32_t> g_two_pass_list_entries{0};          /* test aid, see fr_d
 
 bool valid_tile(int tile) {
     switch (tile) {
-    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 12: case 6401: case 3202: case 1604: case 808:
+    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 12: case 13: case 6401: case 3202: case 1604: case 808:
         return true;
     default:
         return false;
@@ -115,7 +115,7 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     o = default_opts();
     if (!in) return FR_OK;
     if (in->size < sizeof(fr_render_opts)) return fail(FR_ERR_INVALID_ARGUMENT, "fr_render_opts.size is too small (use fr_render_opts_init)");
-    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 11, 12, 6401, 3202, 1604 or 808");
+    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 6401, 3202, 1604 or 808");
     if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
     if (in->refill_minrun < -1 || in->refill_quit16 < -1 || in->refill_quit16 == 0 || in->refill_quit16 > 16)
@@ -145,6 +145,10 @@ int Ctx::create(int device) {
         prio_greatest = 0;
     }
     HIP_TRY(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, prio_greatest));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sample_counters), 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sample_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sample_result), 8 * sizeof(unsigned long long), hipHostMallocMapped));
     hip_device = device;
     return FR_OK;
 }
@@ -172,7 +176,11 @@ void Ctx::destroy() {
     }
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
-    for (hipStream_t *st : {&stream, &stream2, &copy_stream}) {
+    if (sample_counters) (void)hipFree(sample_counters);
+    if (sample_result) (void)hipHostFree(sample_result);
+    sample_counters = sample_result = nullptr;
+    for (ViewChoice &v : view_choices) v = ViewChoice();
+    for (hipStream_t *st : {&stream, &stream2, &copy_stream, &aux_stream}) {
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
@@ -389,12 +397,12 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
      * once 24 lanes are free and 8 iterations were done */
     p.refill_minrun = o.refill_minrun < 0 ? 32u : (uint32_t)o.refill_minrun;
     p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
-    p.queue_minrun = (o.refill_minrun < 0 || o.tile == 11 || o.tile == 12) ? 8u : (uint32_t)o.refill_minrun;
+    p.queue_minrun = (o.refill_minrun < 0 || o.tile == 11 || o.tile == 12 || o.tile == 13) ? 8u : (uint32_t)o.refill_minrun;
     /* tile 11: minrun = the first pass's episode length, quit16 = the lanes (in 16ths of a wave) a tile must
      * keep running to stay in the first pass; the second pass keeps its own defaults */
-    p.first_keep = ((o.tile == 11 || o.tile == 12) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
-    p.two_pass_cap = ((o.tile == 11 || o.tile == 12) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
-    p.queue_want = (o.refill_quit16 < 0 || o.tile == 11 || o.tile == 12) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
+    p.first_keep = ((o.tile == 11 || o.tile == 12 || o.tile == 13) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
+    p.two_pass_cap = ((o.tile == 11 || o.tile == 12 || o.tile == 13) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
+    p.queue_want = (o.refill_quit16 < 0 || o.tile == 11 || o.tile == 12 || o.tile == 13) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
     {
         /* tuning aid: the second pass's own policy under the two-pass render (whose fr_set_refill_policy numbers
          * steer the first pass): FR_DEBUG_QUEUE_WANT / FR_DEBUG_QUEUE_MINRUN */
@@ -504,6 +512,92 @@ int check_precision(int precision) {
     return FR_OK;
 }
 
+std::atomic<int> g_dispatch_sampling{1};
+
+/* Which kernel for a large launch?  Decided from the IMAGE, not from the algorithm's name.  A sample of 16 x 16 tiles
+ * of the launch goes through the plain loop (view_sample_kernel; ~20-70 us, on a stream of the library's own so that
+ * it never waits behind the caller's queue) and tells, for the tiles it saw:
+ *   capped    the share of pixels still running at the sample's cap (interior, or deep boundary);
+ *   waste     the lane-iterations that finishing the stragglers of thinned-out tiles IN PLACE would idle away, as a
+ *             share of the work — what the two-pass render's lists exist to save;
+ *   mean      executed iterations per pixel (x pixels / the first pass's rate = an estimate of the render's time).
+ * Three kernels (measured on 13 views x 2 precisions, tools/two_pass_views.py, profiles/r03_kernel_choice_views.txt):
+ *   two passes        pay ~40 us for their lists and second kernel; taken when the waste they save is worth more;
+ *   first pass alone  (7-tile strips in episodes, frozen lanes finished once per tile, nothing handed over): 10-13 % ahead
+ *                     of the strip kernel on views of short orbits, level with it on long ones;
+ *   strips            1-3 % ahead on interior-heavy views (its loop is 6.5 vector instructions per iteration from the first).
+ * Only for launches large enough for the answer to matter and the sample to be cheap beside them; the last few (view,
+ * launch) pairs are remembered, so re-rendering a view — a GUI changing colours (src/gui.rs:183-203), bench.py's
+ * steps — samples once.  Returns 1 two passes, 2 first pass alone, 0 strips, -1 no opinion.  This is the one
+ * host-blocking step of the device-pointer entry points (first frame of a new view, images of 4096 x 2048 pixels and
+ * more); fr_set_dispatch_sampling(0) removes it. */
+constexpr uint64_t kSampleMinTiles = 131072;
+constexpr uint32_t kSampleCap = 4096;
+
+static uint64_t view_key(const fr_config *cfg, const fr_kparams &p, int precision) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void *data, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(data);
+        for (size_t k = 0; k < n; k++) h = (h ^ b[k]) * 1099511628211ull;
+    };
+    mix(cfg, sizeof *cfg);
+    const uint32_t grid[8] = {p.ncols, p.nrows, p.x_first, p.x_stride, p.block_rows, p.y_first, p.y_stride, (uint32_t)precision};
+    mix(grid, sizeof grid);
+    return h ? h : 1;
+}
+
+int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[6]) {
+    std::lock_guard<std::mutex> lk(ctx.sample_mu);
+    void *d_result = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_result, ctx.sample_result, 0));
+    const uint32_t cap_s = p.iterations < kSampleCap ? p.iterations : kSampleCap;
+    HIP_TRY(fr_launch_view_sample(p, precision, 16, cap_s, 64, 48, ctx.sample_counters, static_cast<unsigned long long *>(d_result),
+                                  ctx.aux_stream));
+    HIP_TRY(hipStreamSynchronize(ctx.aux_stream));
+    for (int k = 0; k < 6; k++) out[k] = (double)__atomic_load_n(ctx.sample_result + k, __ATOMIC_RELAXED);
+    return FR_OK;
+}
+
+static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, int precision, const Opts &o, bool *one_band) {
+    *one_band = false;
+    if (o.tile != 0 || !g_dispatch_sampling.load()) return -1;
+    const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
+    if (tiles < kSampleMinTiles) return -1;
+    fr_kparams q = p; /* would two passes be possible at all? */
+    if (!fr_wants_two_pass(q, precision, 0, 1)) return -1;
+    const uint64_t key = view_key(cfg, p, precision);
+    {
+        std::lock_guard<std::mutex> lk(ctx.sample_mu);
+        for (const Ctx::ViewChoice &v : ctx.view_choices)
+            if (v.key == key) {
+                *one_band = v.one_band;
+                return v.two_pass;
+            }
+    }
+    double st[6];
+    if (sample_view(ctx, p, precision, st) != FR_OK || st[1] <= 0.0) return -1; /* no opinion rather than a failed render */
+    const double lanes = 64.0 * st[2];
+    const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes;
+    /* the render's time, roughly: the first pass runs ~4.5e12 (f32) / 3e12 (f64) pixel-iterations a second */
+    const double est_us = mean * (double)p.ncols * (double)p.nrows / (precision == FR_PRECISION_F32 ? 4.5e6 : 3.0e6);
+    int choice;
+    if (capped >= 0.10 && waste < 0.01)
+        choice = 0; /* long orbits dominate and tiles stay full: the strip kernel's ground */
+    else if (waste * est_us >= 400.0)
+        choice = 1; /* stragglers worth more than the lists cost: the second pass recovers about a fifth of the idled
+                     * lane-time (it is itself 47 lanes of 64 busy, at twice the first pass's cost per iteration), and its
+                     * lists, memsets and second kernel cost ~80 us whatever it finds */
+    else
+        choice = 2;
+    std::lock_guard<std::mutex> lk(ctx.sample_mu);
+    Ctx::ViewChoice &slot = ctx.view_choices[ctx.view_next++ % Ctx::kViewChoices];
+    /* long orbits: workgroups of four strips (28 tiles) differ too much in cost to balance over the chip — C2 through
+     * the first pass alone: 14.2 ms with four strips per workgroup, strips 13.3 (tools/c2c3_choice.py) */
+    *one_band = mean >= 128.0;
+    slot.key = key, slot.two_pass = choice, slot.lane_fraction = st[0] / st[1], slot.one_band = *one_band;
+    return choice;
+}
+
 /* device-pointer render of an arbitrary local grid; no host synchronisation, no shared scratch except
  * the palette slot `ctx` lends: re-entrant */
 int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, const Opts &o, void *d_out,
@@ -514,15 +608,23 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
-    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 12;
-    const bool want_two_pass = fr_wants_two_pass(p, precision, o.tile);
-    const bool want_queue = want_two_pass || fr_wants_work_queue(p, o.tile);
+    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 13;
+    bool one_band = false;
+    const int hint = choose_kernel(ctx, cfg, p, precision, o, &one_band);
+    const bool want_two_pass = fr_wants_two_pass(p, precision, o.tile, hint);
+    p.first_one_band = one_band ? 1u : 0u;
+    {
+        static const int dbg = getenv("FR_DEBUG_FIRST_ONE_BAND") ? atoi(getenv("FR_DEBUG_FIRST_ONE_BAND")) : -1; /* tuning aid */
+        if (dbg >= 0) p.first_one_band = dbg ? 1u : 0u;
+    }
+    const bool want_lists = want_two_pass && !p.first_only;
+    const bool want_queue = want_lists || fr_wants_work_queue(p, o.tile);
     if (want_palette || want_queue) {
         int rc = ctx.acquire_palette(&slot);
         if (rc != FR_OK) return rc;
     }
     SurvSlot *surv = nullptr;
-    if (want_two_pass) {
+    if (want_lists) {
         /* room for a quarter of the pixels (C4 leaves a tenth); what does not fit is finished by the first
          * pass itself, so the size is a matter of speed only */
         const uint64_t npix = (uint64_t)p.ncols * p.nrows;
@@ -1126,6 +1228,35 @@ int fr_set_loop_mode(int mode) {
     if (mode != -1 && mode != 0 && mode != 2 && mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "loop mode must be -1 (auto), 0, 2 or 4");
     g_loop_mode.store(mode);
+    return FR_OK;
+}
+
+int fr_set_dispatch_sampling(int enabled) {
+    g_dispatch_sampling.store(enabled ? 1 : 0);
+    return FR_OK;
+}
+
+/* what choose_kernel measures, for tools and tests: out[0..5] = executed iterations, 64 x sum of per-tile maxima, tiles
+ * sampled, lanes at the sample's cap (1024), lanes handed over after a 64-iteration episode (keep 48), lane-iterations
+ * wasted by finishing those in place; out[6] = out[0] / out[1], the useful-lane fraction of one tile per wave */
+int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]) {
+    if (!cfg || !out) return fail(FR_ERR_INVALID_ARGUMENT, "cfg or out is NULL");
+    int rc = check_precision(precision);
+    if (rc != FR_OK) return rc;
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
+    if (rc != FR_OK) return rc;
+    fr_kparams p;
+    fill_params(cfg, default_opts(), p);
+    p.nrows = cfg->height;
+    p.block_rows = cfg->height ? cfg->height : 1;
+    p.y_stride = 0;
+    if (p.ncols == 0 || p.nrows == 0) return fail(FR_ERR_INVALID_ARGUMENT, "empty image");
+    rc = sample_view(*ctx, p, precision, out);
+    if (rc != FR_OK) return rc;
+    out[6] = out[1] > 0.0 ? out[0] / out[1] : 0.0;
+    out[7] = 0.0;
     return FR_OK;
 }
 

@@ -86,6 +86,21 @@ struct Ctx {
     Scratch rgb, z, iters, misc;
     PaletteSlot palette_slots[kPaletteSlots];
     SurvSlot surv_slots[kSurvSlots];
+    /* view sample (fr_api.hip: choose_kernel): a stream of its own — the sample must not wait behind whatever the
+     * caller has queued on its stream — five device counters, four host-mapped result words, a few remembered views */
+    hipStream_t aux_stream = nullptr;
+    unsigned long long *sample_counters = nullptr; /* device */
+    unsigned long long *sample_result = nullptr;   /* pinned host memory, mapped */
+    std::mutex sample_mu;
+    struct ViewChoice {
+        uint64_t key = 0;
+        int two_pass = -1;
+        bool one_band = false;
+        double lane_fraction = 0.0;
+    };
+    static constexpr int kViewChoices = 8;
+    ViewChoice view_choices[kViewChoices];
+    unsigned view_next = 0;
     std::mutex palette_mu; /* guards both rings */
     std::condition_variable slot_cv; /* a slot of either ring was released */
     unsigned palette_next = 0, surv_next = 0;

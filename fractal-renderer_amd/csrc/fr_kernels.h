@@ -82,6 +82,9 @@ struct fr_kparams {
     uint32_t first_cap;    /* length of a first-pass episode */
     uint32_t first_keep;   /* a tile stays in the first pass while at least this many of its lanes are running */
     uint32_t two_pass_cap; /* the caller's wish for first_cap (0 = the default) */
+    uint32_t first_only;   /* 1: the first pass keeps every tile to its end (no lists, no second pass) */
+    uint32_t first_one_band; /* 1: one 7-tile strip per workgroup whatever the launch size (views of long orbits: workgroups of
+                              * 28 tiles differ too much in cost to balance) */
     uint32_t surv_sub_capacity;
     void *surv_z;           /* T[2] per entry: the position after first_cap iterations */
     uint32_t *surv_pos;     /* uint32[2] per entry: output column, output row */
@@ -129,11 +132,18 @@ bool fr_wants_work_queue(const fr_kparams &p, int tile);
 /* Would fr_launch_escape(p, ..., FR_OUT_RGB, ..., tile) render in two passes if the survivor lists were set?
  * (The caller then lends them — fr_two_pass_bytes() says how large for `entries` per list — and zeroes
  * surv_counts and work_counter on the launch stream.)  Sets p.first_cap when it answers yes. */
-bool fr_wants_two_pass(fr_kparams &p, int precision, int tile);
+bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint = -1); /* hint (tile 0 only): -1 none, 0 strips, 1 two passes, 2 the first pass alone */
 struct fr_two_pass_layout {
     size_t z_off, pos_off, cnt_off, c_off, counts_off, total; /* byte offsets into one allocation */
 };
 fr_two_pass_layout fr_two_pass_bytes(const fr_kparams &p, int precision, uint32_t sub_capacity);
+
+/* View sample (fr_kernels.hip: view_sample_kernel): side x side 8x8 tiles of the launch through the plain loop capped
+ * at cap_s; the last wave writes {executed iterations, 64 x sum of per-tile maxima, tiles, lanes at the cap, lanes a first
+ * episode of `episode` iterations would hand over (tiles with fewer than `keep` lanes left), lane-iterations wasted by
+ * finishing those in place} to `result` (host-mapped) and zeroes `counters` (8 device words, zero before the first use). */
+hipError_t fr_launch_view_sample(const fr_kparams &p, int precision, uint32_t side, uint32_t cap_s, uint32_t episode, uint32_t keep,
+                                 unsigned long long *counters, unsigned long long *result, hipStream_t stream);
 
 /* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
  * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */

@@ -30,6 +30,8 @@
  */
 #include "fr_kernels.h"
 
+#include <cmath>
+
 #include <cstdlib>
 
 #include "fr_math.h"
@@ -1198,43 +1200,62 @@ __device__ __forceinline__ bool lane_in(unsigned long long m) {
 }
 
 /* Blocks of M unchecked scaled iterations for the lanes of `mask` (a subset of EXEC, not empty), one |z|^2 <= T
- * test per block: a lane that fails it freezes with the state, t = A + B and count it has at that moment.  Ends after
+ * test per block: a lane that fails it freezes with the state and t = A + B it has at that moment, and its count is
+ * SET then — to `base` + M x the blocks run so far — by a scalar handler on the blocks in which EXEC changed; lanes
+ * that keep running carry no count (the caller knows it: base + M x nblocks).  26 vector instructions per block,
+ * 6.5 per iteration — the strip kernel's fast path — at 5 scalar ones: for the tiles that stay past their first episode
+ * (the asm path's loop counts per lane, 27 + 3: right for tiles that are gone after a block or two).  Ends after
  * `nblocks` or when no lane runs; returns the lanes that passed every test. */
-#define FR_FB_ASM(SFX, BLOCK_ITS, STEP)                \
+#define FR_FB_ASM(SFX, BLOCK_ITS, MSHIFT)              \
     "s_mov_b64 %[sorig], exec\n"                       \
     "s_mov_b64 exec, %[mask]\n"                        \
     ".Lfb_%=:\n" BLOCK_ITS                             \
     "v_add_" SFX " %[t], %[A], %[B]\n"                 \
-    "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
+    "s_mov_b64 %[sprev], exec\n"                       \
     "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
-    "s_cbranch_execz .Lfbd_%=\n"                       \
+    "s_xor_b64 %[sdiff], %[sprev], exec\n"             \
+    "s_cbranch_scc1 .Lfbr_%=\n"                        \
+    ".Lfbc_%=:\n"                                      \
     "s_sub_u32 %[k], %[k], 1\n"                        \
     "s_cbranch_scc0 .Lfb_%=\n"                         \
+    "s_branch .Lfbd_%=\n"                              \
+    ".Lfbr_%=:\n"                                      \
+    "s_sub_u32 %[stmp], %[n0], %[k]\n"                 \
+    "s_lshl_b32 %[stmp], %[stmp], " MSHIFT "\n"        \
+    "s_add_u32 %[stmp], %[stmp], %[base]\n"            \
+    "s_mov_b64 %[sprev], exec\n"                       \
+    "s_mov_b64 exec, %[sdiff]\n"                       \
+    "v_cvt_f32_u32 %[cnt], %[stmp]\n"                  \
+    "s_mov_b64 exec, %[sprev]\n"                       \
+    "s_cbranch_execnz .Lfbc_%=\n"                      \
     ".Lfbd_%=:\n"                                      \
     "s_mov_b64 %[srun], exec\n"                        \
     "s_mov_b64 exec, %[sorig]\n"
 
 template <typename T, int M>
-__device__ __forceinline__ unsigned long long first_blocks(unsigned long long mask, uint32_t nblocks, T &X, T &Y, T &A, T &B,
-                                                           T &t, float &cnt, T c2re, T c2im, typename UBits<T>::type t4lim) {
+__device__ __forceinline__ unsigned long long first_blocks(unsigned long long mask, uint32_t nblocks, uint32_t done_before, T &X, T &Y,
+                                                           T &A, T &B, T &t, float &cnt, T c2re, T c2im,
+                                                           typename UBits<T>::type t4lim) {
     T q;
-    unsigned long long sorig, srun;
-    uint32_t k = __builtin_amdgcn_readfirstlane(nblocks) - 1u;
+    unsigned long long sorig, srun, sprev, sdiff;
+    const uint32_t n0 = __builtin_amdgcn_readfirstlane(nblocks), base = __builtin_amdgcn_readfirstlane(done_before);
+    uint32_t k = n0 - 1u, stmp;
 #define FR_FB_OPERANDS                                                                                           \
     : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),            \
-      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(k)                                                      \
-    : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask)                                   \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [k] "+s"(k),         \
+      [stmp] "=&s"(stmp)                                                                                         \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(n0), [base] "s"(base)   \
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
         if constexpr (M == 4)
-            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_FB_OPERANDS);
+            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "2") FR_FB_OPERANDS);
         else
-            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "2.0") FR_FB_OPERANDS);
+            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "1") FR_FB_OPERANDS);
     } else {
         if constexpr (M == 4)
-            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_FB_OPERANDS);
+            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "2") FR_FB_OPERANDS);
         else
-            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_FB_OPERANDS);
+            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "1") FR_FB_OPERANDS);
     }
     return srun;
 }
@@ -1276,14 +1297,16 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
 }
 
 /* The common case of a tile, start to finish, in one asm block — a full tile of a strip that may use the scaled
- * form, no start beyond T: the first episode (`nblk` blocks of M unchecked iterations) and, if every lane has
+ * form, no start beyond the limit: the first episode (`nblk` blocks of M unchecked iterations) and, if every lane has
  * frozen by its end (three tiles in five on C4 are gone after ONE block), their exact last iterations.  The scalar
  * unit is a co-limiter of the f32 render (one scalar instruction per ~4 cycles per SIMD against ~2.4 for an f32
  * vector one; profiles/r03_c4_first_pass_classes.txt): on this path the scalar work is the loops' own control
  * and a dozen instructions besides.  Returns how far it got; the state is valid for the general path to go on from:
  *   0  every lane escaped (state = `next`, cnt = its index + 1)
  *   1  lanes still run after the first episode (`srun`): further episodes or a hand-over
- *   2  nothing was done: some start lies beyond T
+ *   2  nothing was done: some start lies beyond the LIMIT (a start merely beyond T stays here, frozen from the
+ *      start with a count of 0: the exact loop takes it from iteration 0, and the test "did its last iteration
+ *      escape" cannot fire for it because its |z|^2 is within the limit)
  *   3  64 exact iterations did not finish everybody (`srun` = the lanes still live) */
 #define FR_SC_IT0(SFX)                             \
     "v_add_" SFX " %[t], %[A], -%[B0]\n"           \
@@ -1294,17 +1317,28 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
     "v_mul_" SFX " %[B], %[Y], %[Y]\n"
 /* REST_ITS = the block's iterations after its first; the first block's first iteration reads Y0 / B0 where they
  * lie (no copies) and its count is set, not added */
-#define FR_TILE_ASM(SFX, REST_ITS, STEP)               \
+#define FR_TILE_ASM(SFX, MOVT, REST_ITS, STEP)         \
     "s_load_dwordx2 %[fa], %[kargs], %[offa]\n"        \
     "s_load_dwordx2 %[fb], %[kargs], %[offb]\n"        \
     "s_load_dword %[fk], %[kargs], %[offk]\n"          \
     "v_add_" SFX " %[X], %[sre], %[sre]\n"             \
     "v_mul_" SFX " %[A], %[X], %[X]\n"                 \
     "v_add_" SFX " %[t], %[A], %[B0]\n"                \
+    "v_mov_b32 %[cnt], 0\n"                            \
     "s_mov_b32 %[st], 2\n"                             \
-    "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"           \
+    "v_cmp_lt_" SFX " vcc, %[lim4], %[t]\n"            \
     "s_cbranch_vccnz .Ltout_%=\n"                      \
     "s_mov_b64 %[sorig], exec\n"                       \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_xor_b64 %[srun], %[sorig], exec\n"              \
+    "s_cbranch_scc0 .Ltgo_%=\n"                        \
+    "s_mov_b64 vcc, exec\n"                            \
+    "s_mov_b64 exec, %[srun]\n"                        \
+    MOVT " %[Y], %[Y0]\n"                              \
+    MOVT " %[B], %[B0]\n"                              \
+    "s_mov_b64 exec, vcc\n"                            \
+    "s_cbranch_execz .Ltnone_%=\n"                     \
+    ".Ltgo_%=:\n"                                      \
     FR_SC_IT0(SFX) REST_ITS                            \
     "v_add_" SFX " %[t], %[A], %[B]\n"                 \
     "v_mov_b32 %[cnt], " STEP "\n"                     \
@@ -1325,6 +1359,8 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
     "s_mov_b32 %[st], 1\n"                             \
     "s_cmp_lg_u64 %[srun], 0\n"                        \
     "s_cbranch_scc1 .Ltout_%=\n"                       \
+    ".Ltnone_%=:\n"                                    \
+    "s_mov_b64 exec, %[sorig]\n"                       \
     "s_mov_b32 %[st], 0\n"                             \
     "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"               \
     "s_cbranch_execz .Ltfd_%=\n"                       \
@@ -1343,9 +1379,6 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
     ".Ltout_%=:\n"                                     \
     "s_waitcnt lgkmcnt(0)\n"
 
-/* Also fetches the colour filter's scalars for the caller — prim32[0..1], prim32[2] and filt_lo32, filt_k32 —
- * from the kernel-argument segment: issued before the loops, waited for behind them, so that they cost neither
- * resident scalar registers (they were spilled to vector lanes: 16 v_readlane per tile) nor exposed latency. */
 template <typename T, int M>
 __device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, T c2re, T c2im, typename UBits<T>::type t4lim,
                                               typename UBits<T>::type lim4, KArgs kargs, T &X, T &Y, T &A, T &B, T &t, float &cnt,
@@ -1366,14 +1399,14 @@ __device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, 
     : "vcc", "scc", "memory"
     if constexpr (sizeof(T) == 8) {
         if constexpr (M == 4)
-            asm volatile(FR_TILE_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_TILE_OPERANDS);
         else
-            asm volatile(FR_TILE_ASM("f64", FR_SC_IT("f64"), "2.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f64", "v_mov_b64", FR_SC_IT("f64"), "2.0") FR_TILE_OPERANDS);
     } else {
         if constexpr (M == 4)
-            asm volatile(FR_TILE_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_TILE_OPERANDS);
         else
-            asm volatile(FR_TILE_ASM("f32", FR_SC_IT("f32"), "2.0") FR_TILE_OPERANDS);
+            asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32"), "2.0") FR_TILE_OPERANDS);
     }
     return st;
 }
@@ -1479,7 +1512,8 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         fd0 = P.filt_d32[0], fd1 = P.filt_d32[2], fd2 = P.filt_d32[1];
         asm volatile("" : "+v"(fd0), "+v"(fd1), "+v"(fd2)); /* vector registers from here on */
     }
-    const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_keep; /* the host guarantees 0 < k1 < cap < 2^24 */
+    /* the host guarantees 0 < k1 < cap < 2^24; first_only: no tile is ever handed over (keep = 0), every lane finishes here */
+    const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_only ? 0u : p.first_keep;
     const bool julia = p.algo == 2;
     const T jre = (T)p.julia_re, jim = (T)p.julia_im;
     const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
@@ -1578,8 +1612,9 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                 unsigned long long handed = 0ull;
                 if (st != 3u) {
                     /* episodes of k1 iterations for as long as the tile is worth a wave of its own — at least `keep`
-                     * lanes still running; a tile still here after 8 episodes is most likely inside a filled set: from
-                     * then on every episode is twice the last, up to 8 x k1 */
+                     * lanes still running; a tile still here after two episodes is most likely inside a filled set: from
+                     * then on every episode is twice the last, up to 16 x k1 (a tile that thins out in mid-episode idles
+                     * for at most as long as it has already run; 1024 iterations take 5 episodes instead of 11) */
                     uint32_t len = k1;
                     bool first = st == 1u; /* the asm path has run the first episode */
                     while (run != 0ull) {
@@ -1587,7 +1622,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                             const uint32_t left = cap - done;
                             const uint32_t nblk = (left < len ? left : len) / (uint32_t)M;
                             if (nblk == 0u) break; /* fewer than M iterations to the cap: the exact loop below runs them */
-                            run = first_blocks<T, M>(run, nblk, X, Y, A, B, t, cnt, c2re, c2im, t4lim);
+                            run = first_blocks<T, M>(run, nblk, done, X, Y, A, B, t, cnt, c2re, c2im, t4lim);
                             done += nblk * (uint32_t)M;
                         } else {
                             done = k1;
@@ -1595,9 +1630,11 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                         }
                         if (run == 0ull || cap - done < (uint32_t)M) break;
                         if ((uint32_t)__builtin_popcountll(run) < keep) break;
-                        if (done >= 8u * k1 && len < 8u * k1) len += len;
+                        if (done >= 2u * k1 && len < 16u * k1) len += len;
                     }
                     if (st == 1u && done == 0u) done = k1;
+                    /* lanes that ran through those episodes carry no count of their own (first_blocks): it is `done` */
+                    if (run != 0ull) cnt = lane_in(run) ? (float)done : cnt;
                     /* hand the running lanes over: position after `done` iterations, recursive()'s own state */
                     if (run != 0ull && cap - done >= (uint32_t)M) {
                         FR_COLD_PARAMS(kp);
@@ -2526,37 +2563,12 @@ hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t 
      * workgroups to balance over the chip: at 8192^2 (37 000 of them for 8192 resident waves) C4's dust takes 0.86 ms
      * instead of 0.72, and filled sets, whose workgroups differ a thousandfold in cost, lose more.  So: only while
      * at least 131 072 workgroups remain. */
-    const int bands = gx * ((row_tiles + 3) / 4) >= 131072 ? 4 : 1;
+    const int bands = (!p.first_one_band && gx * ((row_tiles + 3) / 4) >= 131072) ? 4 : 1;
     const uint64_t row_blocks = (row_tiles + bands - 1) / bands;
     const uint64_t gy = row_blocks < 32768 ? row_blocks : 32768;
     const uint64_t gz = (row_blocks + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
-    /* tuning aid: FR_DEBUG_FIRST_LDS = bytes of (unused) dynamic LDS per workgroup, to study the first pass at a
-     * lower occupancy (160 KB per CU: 40960 -> 1 wave per SIMD, 20480 -> 2, 10240 -> 4, ...) */
-    static const size_t dbg_lds = [] {
-        const char *e = getenv("FR_DEBUG_FIRST_LDS");
-        return e ? (size_t)atol(e) : (size_t)0;
-    }();
-    static const int dbg_bands = [] {
-        const char *e = getenv("FR_DEBUG_FIRST_BANDS");
-        return e ? atoi(e) : 0;
-    }();
-    if ((dbg_bands == 2 || dbg_bands == 1) && p.loop_mode == 4 && bands == 4 && !v1) {
-        const uint64_t rbk = (row_tiles + dbg_bands - 1) / dbg_bands;
-        const uint64_t gyk = rbk < 32768 ? rbk : 32768;
-        const dim3 gk((uint32_t)gx, (uint32_t)gyk, (uint32_t)((rbk + gyk - 1) / gyk));
-        if (dbg_bands == 2)
-            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 2>), gk, dim3(64), dbg_lds, stream, p, out);
-        else
-            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), gk, dim3(64), dbg_lds, stream, p, out);
-    } else if (dbg_bands == 8 && p.loop_mode == 4 && bands == 4 && !v1) {
-        const uint64_t rb8 = (row_tiles + 7) / 8;
-        const uint64_t gy8 = rb8 < 32768 ? rb8 : 32768;
-        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 8>), dim3((uint32_t)gx, (uint32_t)gy8, (uint32_t)((rb8 + gy8 - 1) / gy8)), dim3(64), dbg_lds, stream, p, out);
-    } else if (dbg_lds && p.loop_mode == 4 && bands == 4 && !v1) {
-        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), dbg_lds, stream, p, out);
-    } else
     if (v1 && p.loop_mode == 4 && bands == 4) /* round 2's first pass, kept for comparison (tile 12) */
         hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
     else if (v1 && p.loop_mode == 4)
@@ -2571,6 +2583,7 @@ hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t 
         hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (p.first_only) return hipSuccess; /* nothing was handed over: there are no lists */
     if (p.loop_mode == 4) return launch_queue_form<T, 4, 1>(p, out, stream);
     return launch_queue_form<T, 2, 1>(p, out, stream);
 }
@@ -2626,7 +2639,7 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 template <typename T>
 hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream,
                             const char *&name) {
-    if (p.out_in_place && tile > 12) tile = 0; /* only the strip kernels know in-place addressing */
+    if (p.out_in_place && tile > 13) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
         name = FR_KNAME("escape_kernel", "64x1");
@@ -2644,17 +2657,17 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         /* strip length by image size: long strips amortise the per-workgroup setup, short ones
          * keep every SIMD supplied with several waves when the image is small (GUI frames) */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
-        if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
+        if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
             /* Julia views are mostly short orbits with a heavy tail: two passes (see escape_first_kernel; the
              * host asks for it from 65 536 tiles up: fr_wants_two_pass) */
-            name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            name = p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
+                                : FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
             return launch_two_pass<T>(p, out, stream);
         }
         if (tiles >= 262144) {
-            /* Julia views are mostly boundary (few long orbits among many short ones): refill idle
-             * lanes.  Mandelbrot views keep 97 % of their lanes busy without it (measured on the
-             * default view and a 10^6 zoom) and skip the bookkeeping. */
-            if (p.algo == 2 || (p.cycle_shortcut && p.algo == 0)) {
+            /* patch refill: behind the periodicity shortcut, and for the COUNT / ESCAPE outputs of Julia images
+             * (RGB renders of Julia images this large take the two-pass kernels above) */
+            if ((p.algo == 2 && mode != FR_OUT_RGB) || p.cycle_shortcut) {
                 name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
                 return launch_refill<T, 7>(p, mode, out, stream);
             }
@@ -2675,14 +2688,20 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
     case 8:
         name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
+    case 13: /* the first pass alone: no tile is handed over, no lists, no second kernel */
     case 12: /* two passes with round 2's first pass (comparison only) */
-        if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
-            name = FR_KNAME("escape_first_v1_kernel + escape_queue_kernel", "round 2's first pass, then persistent waves over the survivor lists");
-            return launch_two_pass<T>(p, out, stream, true);
+        if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
+            if (tile == 12) {
+                name = FR_KNAME("escape_first_v1_kernel + escape_queue_kernel", "round 2's first pass, then persistent waves over the survivor lists");
+                return launch_two_pass<T>(p, out, stream, true);
+            }
+            name = p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
+                                : FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            return launch_two_pass<T>(p, out, stream);
         }
         [[fallthrough]];
     case 11: /* two passes: strips to first_cap, then the work-queue kernel over the survivors (otherwise as 9) */
-        if (mode == FR_OUT_RGB && p.first_cap != 0 && p.surv_counts && p.work_counter) {
+        if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
             name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
             return launch_two_pass<T>(p, out, stream);
         }
@@ -2733,6 +2752,81 @@ __global__ __launch_bounds__(256) void recursive_batch_kernel(uint32_t iteration
     out_pos[2 * k] = (double)re;
     out_pos[2 * k + 1] = (double)im;
     out_iters[k] = it;
+}
+
+/* ---- view sample: which kernel suits this image? ------------------------------------------------------
+ *
+ * One wave renders ONE 8x8 tile of the launch — `side` x `side` of them on a regular grid over it — through
+ * recursive()'s plain loop, capped at `cap_s` iterations, and adds to six device counters: executed iterations of
+ * its 64 pixels, 64 x the largest of them (what a wave that keeps a tile to its end pays), tiles, lanes that hit
+ * the cap, lanes the two-pass render would hand over after its first episode, and the lane-iterations that finishing
+ * those in place would waste — what fr_api.hip: choose_kernel decides on.  The last wave to finish copies the
+ * totals to `result` (host-mapped) and zeroes the counters for the next sample.  Colours nothing, stores nothing. */
+template <typename T>
+__global__ __launch_bounds__(64) void view_sample_kernel(const fr_kparams p, uint32_t side, uint32_t cap_s, uint32_t episode, uint32_t keep,
+                                                         unsigned long long *counters, unsigned long long *result) {
+    const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
+    const uint32_t ti = blockIdx.x % side, tj = blockIdx.x / side;
+    /* tile origin: the centre of cell (ti, tj) of the grid, aligned down to a multiple of 8 */
+    const uint32_t col0 = (uint32_t)(((uint64_t)(2u * ti + 1u) * p.ncols) / (2u * side)) & ~7u;
+    const uint32_t row0 = (uint32_t)(((uint64_t)(2u * tj + 1u) * p.nrows) / (2u * side)) & ~7u;
+    const uint32_t cx = col0 + lx, r = row0 + ly;
+    const bool valid = cx < p.ncols && r < p.nrows;
+    const double width = (double)p.width, height = (double)p.height;
+    const uint32_t x = p.x_first + cx * p.x_stride;
+    const uint32_t y = p.y_first + (r / p.block_rows) * p.y_stride + r % p.block_rows;
+    const double sre = coord_to_space((double)x, height, (width / height) / 2.0, p.pos_re, p.scale_re);
+    const double sim = coord_to_space((double)y, height, 0.5, p.pos_im, p.scale_im);
+    uint32_t executed = 0;
+    if (valid) {
+        T re = (T)sre, im = (T)sim, r2, i2;
+        const T cre = p.algo == 2 ? (T)p.julia_re : re, cim = p.algo == 2 ? (T)p.julia_im : im;
+        const T lim = (T)p.limit;
+        const uint32_t it = orbit<T>(cap_s, re, im, cre, cim, lim * lim, r2, i2);
+        executed = it < cap_s ? it + 1u : cap_s;
+    }
+    const uint32_t mx = wave_max_u32(executed);
+    unsigned long long sum = executed;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    const unsigned long long capped = (unsigned long long)__builtin_popcountll(__ballot(valid && executed == cap_s));
+    /* what the two-pass render would do with this tile: episodes (the first pass's own schedule: `episode` iterations,
+     * doubling from the third on, up to 16 x) for as long as at least `keep` lanes are still running; at the first
+     * boundary where fewer are, it hands them over.  Finishing them in place instead costs the wave (longest - boundary)
+     * more iterations, of which only the running lanes' own are useful */
+    uint32_t e = episode, len = episode, nrun = 0;
+    bool hands_over = false;
+    while (e < mx) { /* wave-uniform */
+        nrun = (uint32_t)__builtin_popcountll(__ballot(executed > e));
+        if (nrun < keep) {
+            hands_over = nrun > 0u;
+            break;
+        }
+        if (e >= 2u * episode && len < 16u * episode) len += len;
+        e += len;
+    }
+    unsigned long long rest = executed > e ? executed - e : 0u;
+    for (int off = 32; off > 0; off >>= 1) rest += __shfl_down(rest, off, 64);
+    if (lane == 0) {
+        atomicAdd(counters + 0, sum);
+        atomicAdd(counters + 1, 64ull * mx);
+        atomicAdd(counters + 2, 1ull);
+        atomicAdd(counters + 3, capped);
+        if (hands_over) {
+            atomicAdd(counters + 4, (unsigned long long)nrun);
+            atomicAdd(counters + 5, 64ull * (mx - e) - rest); /* lane-iterations wasted by finishing in place */
+        }
+        __threadfence();
+        const unsigned long long done = atomicAdd(counters + 7, 1ull);
+        if (done + 1ull == (unsigned long long)gridDim.x) { /* the last wave: publish, reset */
+            __threadfence();
+            for (int k = 0; k < 6; k++) {
+                const unsigned long long v = atomicExch(counters + k, 0ull);
+                __hip_atomic_store(result + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            atomicExch(counters + 7, 0ull);
+            __threadfence_system();
+        }
+    }
 }
 
 /* palette[i] for i = 0 .. iterations: the outside colour of escape index i when smooth == false
@@ -2834,18 +2928,32 @@ bool fr_wants_work_queue(const fr_kparams &p, int tile) {
     return tile == 10;
 }
 
-bool fr_wants_two_pass(fr_kparams &p, int precision, int tile) {
-    (void)precision;
+bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint) {
     p.first_cap = 0;
+    p.first_only = 0;
     if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
     if (p.loop_mode == 0 || p.iterations >= (1u << 24)) return false; /* as for the work-queue kernel */
     if (p.ncols == 0 || p.nrows == 0 || (uint64_t)p.ncols * p.nrows > 0xFFF00000ull) return false;
+    if (p.algo == 2 && tile == 0) {
+        /* a Julia constant the scaled loop may not run with (a component that is zero, tiny or huge — the dendrite c = i):
+         * the first pass would take its plain-loop fallback on every strip; the strip kernel is the better plain loop */
+        const double lo = precision == 1 ? 0x1p-30 : 0x1p-300, hi = precision == 1 ? 0x1p30 : 0x1p400;
+        const double jr = precision == 1 ? std::fabs((double)(float)p.julia_re) : std::fabs(p.julia_re);
+        const double ji = precision == 1 ? std::fabs((double)(float)p.julia_im) : std::fabs(p.julia_im);
+        if (!(jr >= lo && jr <= hi && ji >= lo && ji <= hi)) return false;
+    }
     if (tile == 0) {
         /* the default dispatch: Julia images from 2048^2 up.  Measured (tools/two_pass_sizes.py, C4's view, f32 /
          * f64, against the strips the default would otherwise pick): 65 536 tiles 0.17 / 0.21 ms against 0.18 / 0.30,
          * 131 072 tiles 0.17 / 0.22 against 0.20 / 0.33; at 32 768 tiles and below the strips win in f32 */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
-        if (p.algo != 2 || tiles < 65536) return false;
+        if (tiles < 65536) return false;
+        /* which of the two suits the IMAGE is measured where that pays (hint: 1 two passes, 0 strips — fr_api.hip:
+         * choose_kernel); without a measurement, by the algorithm: Julia views are mostly short orbits with a heavy tail */
+        if (hint == 0 || (hint < 0 && p.algo != 2)) return false;
+        p.first_only = hint == 2 ? 1u : 0u;
+    } else if (tile == 13) {
+        p.first_only = 1u;
     } else if (tile != 11 && tile != 12) {
         return false;
     }
@@ -2918,6 +3026,16 @@ hipError_t fr_launch_colour(const fr_kparams &p, const double *z, const uint32_t
     const uint64_t blocks = (n + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(colour_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, p, z, iters, n, rgb);
+    return hipGetLastError();
+}
+
+hipError_t fr_launch_view_sample(const fr_kparams &p, int precision, uint32_t side, uint32_t cap_s, uint32_t episode, uint32_t keep,
+                                 unsigned long long *counters, unsigned long long *result, hipStream_t stream) {
+    if (side == 0 || p.ncols == 0 || p.nrows == 0) return hipErrorInvalidValue;
+    if (precision == 1)
+        hipLaunchKernelGGL(view_sample_kernel<float>, dim3(side * side), dim3(64), 0, stream, p, side, cap_s, episode, keep, counters, result);
+    else
+        hipLaunchKernelGGL(view_sample_kernel<double>, dim3(side * side), dim3(64), 0, stream, p, side, cap_s, episode, keep, counters, result);
     return hipGetLastError();
 }
 

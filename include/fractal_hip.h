@@ -329,6 +329,19 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
  * pixel footprint. */
 int fr_set_tile(int tile);
 
+/* The default dispatch (tile 0) chooses between strips and two passes from the IMAGE: for launches of 131 072
+ * tiles (4096 x 2048 pixels) and more it renders a sample of 256 tiles through the plain loop (~20 us of device time
+ * on a stream of the library's own, ~40 us of the caller's) and takes two passes when one-tile-per-wave rendering would
+ * keep less than 0.8 of its lanes busy.  The last eight (view, launch) pairs are remembered.  This is the ONE step of
+ * the device-pointer entry points that blocks the calling thread; 0 switches it off (then: two passes for Julia
+ * images from 2048^2 up, strips otherwise, as for smaller launches).  Same bytes either way. */
+int fr_set_dispatch_sampling(int enabled);
+/* Tool / test hook: the sample of the whole image. out[0..5] = executed iterations, 64 x the sum of the tiles' longest
+ * orbits, tiles, lanes at the sample's cap of 1024, lanes the two-pass render would hand over after its first episode,
+ * lane-iterations that finishing those in place would waste; out[6] = out[0] / out[1], the useful-lane fraction of
+ * one-tile-per-wave rendering; out[7] = 0. */
+int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]);
+
 /* Policy of the lane-refilling kernels (tuning studies): an orbit episode may end early, so that
  * idle lanes get new pixels, once quit16/16 of its running lanes (work-queue kernel: of the wave's 64 lanes)
  * have finished and at least `minrun` iterations were done.  With tile 11 the two numbers steer its first pass

@@ -210,6 +210,10 @@ def test_two_pass_render_matches_the_oracle(fr, lib, case):
         for episode, keep16 in ((4, 1), (8, 16), (64, 12), (200, 8), (1000, 4)):
             got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, refill_minrun=episode, refill_quit16=keep16))
             assert np.array_equal(got, want), (case, prec, episode, keep16)
+        # tile 13: the first pass alone (no tile is handed over, no lists, no second kernel), same episode lengths
+        for episode in (-1, 4, 8, 64, 200):
+            got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=13, refill_minrun=episode))
+            assert np.array_equal(got, want), (case, prec, "first pass alone", episode)
         # the shortcut rules the two passes out (the launch takes the patch-refill kernel); no filter / no palette change their colour path
         for kw in (dict(cycle_shortcut=1), dict(colour_filter=0), dict(palette=0)):
             got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, **kw))
@@ -233,7 +237,7 @@ def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, l
     from fractal_renderer_amd import _native
 
     ocfgs = [O.cli_config(2048, 2048, O.JULIA, julia_set=js, iterations=it)
-             for js, it in (((-0.8, 0.156), 600), ((0.285, 0.01), 300), ((-0.4, 0.6), 900), ((-0.8, 0.156), 150), ((0.0, 0.8), 500))]
+             for js, it in (((-0.8, 0.156), 600), ((0.285, 0.01), 300), ((-0.4, 0.6), 900), ((-0.8, 0.156), 150), ((0.001, 0.8), 500))]
     cfgs = [to_fr(fr, c) for c in ocfgs]
     precs = [0, 1, 0, 1, 0]
     want = []
@@ -374,7 +378,7 @@ def test_full_size_mandelbrot_work_queue_kernel_equals_default(fr, lib, view):
     need = 3 * 16384 * 16384
     s = torch.cuda.current_stream()
     imgs = []
-    for tile in (0, 10, 11):
+    for tile in (8, 10, 11):  # 8: the strip kernel by name (the default dispatch samples the view: C2 -> strips, C3 -> either)
         d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
         o = fr.RenderOpts(tile=tile)
         _native.check(lib.fr_set_profiling(1))
@@ -383,7 +387,7 @@ def test_full_size_mandelbrot_work_queue_kernel_equals_default(fr, lib, view):
         name = C.create_string_buffer(160)
         _native.check(lib.fr_last_kernel_name(name, len(name)))
         _native.check(lib.fr_set_profiling(0))
-        assert name.value.startswith({0: b"escape_strip_kernel", 10: b"escape_queue_kernel", 11: b"escape_first_kernel"}[tile]), name.value
+        assert name.value.startswith({8: b"escape_strip_kernel", 10: b"escape_queue_kernel", 11: b"escape_first_kernel"}[tile]), name.value
         imgs.append(d)
     torch.cuda.synchronize()
     assert torch.equal(imgs[0], imgs[1]) and torch.equal(imgs[0], imgs[2])
@@ -450,3 +454,61 @@ def test_scaled_loop_c_magnitude_boundary_f32(fr, lib, mag):
             nan = np.isnan(wz)
             assert np.array_equal(it, wit), (mag, jset, mode)
             assert np.array_equal(nan, np.isnan(z)) and np.array_equal(z.view(np.uint64)[~nan], wz.view(np.uint64)[~nan])
+
+
+def test_default_dispatch_chooses_the_kernel_from_a_sample_of_the_image(fr, lib):
+    """for launches of 131 072 tiles and more the default dispatch renders a sample of 256 tiles and
+    picks strips / the first pass alone / two passes from what it sees — for Mandelbrot views too.  Whatever it picks,
+    the bytes are those of the strip kernel; the choice is remembered per view; fr_set_dispatch_sampling(0) restores the
+    rule by algorithm.  (Device-pointer renders: the host-buffer path renders in bands, which are smaller launches.)"""
+    import ctypes as C
+
+    import torch
+
+    from fractal_renderer_amd import _native
+
+    w, h = 4096, 2048  # exactly 131 072 tiles
+    views = [
+        ("julia dust", dict(algo=O.JULIA, iterations=4096, julia_set=(-0.8, 0.156)), b"escape_first_kernel"),
+        ("mandelbrot default", dict(algo=O.MANDELBROT, iterations=1024), b"escape_strip_kernel"),
+        ("mandelbrot exterior", dict(algo=O.MANDELBROT, iterations=4096, pos=(-1.9, 0.15), scale=(4.0, 4.0)), b"escape_first_kernel<"),
+        ("julia dendrite (c.re = 0: the scaled loop is not admissible)", dict(algo=O.JULIA, iterations=512, julia_set=(0.0, 1.0)),
+         b"escape_strip_kernel"),
+    ]
+    name = C.create_string_buffer(256)
+    out = torch.empty(w * h * 3, dtype=torch.uint8, device="cuda")
+
+    def render(cfg, prec, tile):
+        o = fr.RenderOpts(tile=tile)
+        _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), int(prec), 0, h, out.data_ptr(), out.numel(), None, C.byref(o)))
+        torch.cuda.synchronize()
+        _native.check(lib.fr_last_kernel_name(name, 256))
+        return out.clone(), name.value
+
+    try:
+        _native.check(lib.fr_set_profiling(1))
+        for label, kw, expect in views:
+            algo = kw.pop("algo")
+            ocfg = O.cli_config(w, h, algo, **kw)
+            cfg = to_fr(fr, ocfg)
+            st = (C.c_double * 8)()
+            _native.check(lib.fr_debug_sample_view(C.byref(cfg), 1, st))
+            assert st[2] == 256 and 0.0 < st[6] <= 1.0 and st[0] > 0, (label, list(st))
+            for prec in (fr.Precision.F32, fr.Precision.F64):
+                want, _ = render(cfg, prec, 8)
+                for rep in range(2):  # the second render finds the view remembered
+                    got, kname = render(cfg, prec, 0)
+                    assert torch.equal(got, want), (label, prec, rep)
+                    assert kname.startswith(expect), (label, prec, kname)
+        # sampling off: two passes for Julia, strips for Mandelbrot, whatever the view
+        _native.check(lib.fr_set_dispatch_sampling(0))
+        ocfg = O.cli_config(w, h, O.MANDELBROT, iterations=4096, pos=(-1.9, 0.15), scale=(4.0, 4.0))
+        cfg = to_fr(fr, ocfg)
+        got, kname = render(cfg, fr.Precision.F32, 0)
+        assert kname.startswith(b"escape_strip_kernel"), kname
+        alone, kname = render(cfg, fr.Precision.F32, 13)
+        assert kname.startswith(b"escape_first_kernel<"), kname
+        assert torch.equal(got, alone)
+    finally:
+        _native.check(lib.fr_set_dispatch_sampling(1))
+        _native.check(lib.fr_set_profiling(0))
