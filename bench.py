@@ -159,13 +159,33 @@ def roofline_block(prec_name, launch_px_it, kernel_ms, pixels, kernel_name, traf
     }
 
 
-def traffic_record(cfg, prec_name, view):
+def pmc_record(cfg, prec_name, view, build_id):
+    """The committed rocprofv3 PMC record of this exact configuration (profiles/pmc_counters.json, written by
+    tools/pmc_record.py from the separate --pmc passes of tools/pmc_sq.sh): HBM bytes per launch and vector-issue
+    utilisation.  It is a MEASUREMENT OF ANOTHER RUN, so it is attached only when it was taken with the library
+    that is running now (same build_id) and the line says where it comes from."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
             rec = json.load(f).get("%dx%d_i%d_%s_%s" % (cfg.width, cfg.height, cfg.iterations, prec_name, view))
-            return rec["hbm_bytes_per_launch"] if rec else None
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError):
         return None
+    if not rec or rec.get("build_id") != build_id:
+        return None
+    return rec
+
+
+def roofline_with_pmc(block, rec):
+    """roofline block + what the committed counters of the same build say; traffic stays null without them"""
+    if rec is None:
+        block["traffic"] = None
+        block["traffic_source"] = "none for this build (profiles/pmc_counters.json holds no record with this build_id)"
+        return block
+    block["traffic"] = rec["hbm_bytes_per_launch"]
+    block["traffic_source"] = "profiles/pmc_counters.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, %s, build_id %s; not measured in this run)" % (
+        rec.get("date", "?"), rec["build_id"])
+    block["valu_issue_util"] = rec.get("valu_issue_util")
+    block["valu_issue_util_note"] = rec.get("valu_issue_util_note")
+    return block
 
 
 ROOFLINE_NOTE = ("bound = VECTOR issue rate of the arithmetic type (no MFMA; not HBM: 3 B/pixel written once, see "
@@ -218,19 +238,93 @@ class SingleGpu:
                 "total": total, "kernel": name.value.decode(), "image": img}
 
 
-def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup, edge=16384):
+def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup, edge=16384, cpu_compare=False):
     prec = fr.Precision.F32 if prec_name == "f32" else fr.Precision.F64
     cfg = make_config(fr, view, edge, iterations)
     m = sg.measure(cfg, prec, steps, warmup)
     pixels = cfg.width * cfg.height
+    extra = {}
+    if cpu_compare:
+        # the WHOLE image on the host (C4: 1.2e10 pixel-iterations, a second or two of CPU), byte for byte against the GPU's
+        info, colours, cpu_total = cpu_baseline(bytes(cfg), int(prec), usable_cores(), 1)
+        extra = {"cpu_bytes_identical": bool((m["image"].cpu().numpy() == colours).all()),
+                 "cpu_iteration_sum_identical": bool(cpu_total == m["total"]),
+                 "cpu_seconds": info["seconds"], "cpu_threads": info["threads"]}
     return {
+        **extra,
         "workload": "%s %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (VIEWS[view][0], edge, edge, iterations, prec_name, view, name),
         "value": m["total"] * steps / m["dt"], "unit": "pixel-iterations/s", "steps": steps, "warmup": warmup,
         "ms_per_step": m["ms_per_step"], "dtype": prec_name, "pixel_iterations_per_image": m["total"],
         "mean_iterations_per_pixel": m["total"] / pixels,
-        "roofline": roofline_block(prec_name, m["total"], m["kernel_ms"], pixels, m["kernel"] + " (fused coordinate map + "
-                                   "orbit loop + colour map)", traffic_record(cfg, prec_name, view)),
+        "roofline": roofline_with_pmc(roofline_block(prec_name, m["total"], m["kernel_ms"], pixels, m["kernel"] + " (fused coordinate map + "
+                                                     "orbit loop + colour map)", None), pmc_record(cfg, prec_name, view, fr.build_id())),
     }
+
+
+def gui_latency(fr):
+    """SURVEY.md §8 f2, driver-timed: what a GUI-shaped caller sees — the reference's render thread
+    calls get_image for every redraw (src/gui.rs:56-82) and hands RGBA to egui (:71-72); `S` starts a 2x screenshot
+    on another thread while redraws go on (:322-326).  Per frame shape: the FIRST call of the process for that shape,
+    then median and 95th percentile of 50 calls of the host-buffer entry point into a buffer that exists (kernel +
+    D2H + the call's own overhead, milliseconds), RGB and RGBA; then render + screenshot on two threads at once."""
+    import threading
+
+    import numpy as np
+
+    frames = [("750x500 i=50 (CLI defaults, src/lib.rs:34-50)", 750, 500, 50), ("1500x1000 i=50 (the 2x screenshot of it)", 1500, 1000, 50),
+              ("1920x1080 i=1024", 1920, 1080, 1024), ("3840x2160 i=1024", 3840, 2160, 1024)]
+    out = {}
+    for view in ("default", "julia"):
+        rows = {}
+        for label, w, h, it in frames:
+            cfg = make_config(fr, view, 16, it)
+            cfg.width, cfg.height = w, h
+            rec = {}
+            for fmt, call, ch in (("rgb", lambda b: fr.get_image_rows(cfg, 0, h, fr.Precision.F64, out=b), 3),
+                                  ("rgba", lambda b: fr.get_image_rgba(cfg, fr.Precision.F64, out=b), 4)):
+                buf = np.zeros((h, w, ch), dtype=np.uint8)
+                t0 = time.perf_counter()
+                call(buf)
+                first = (time.perf_counter() - t0) * 1e3
+                ts = []
+                for _ in range(50):
+                    t0 = time.perf_counter()
+                    call(buf)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ts.sort()
+                rec[fmt] = {"first_call_ms": first, "median_ms": ts[25], "p95_ms": ts[47]}
+            rows[label] = rec
+        # render thread + screenshot thread (2x) at once: 30 redraws of 750x500 while 3 screenshots of 1500x1000 render
+        small = make_config(fr, view, 16, 50)
+        small.width, small.height = 750, 500
+        big = make_config(fr, view, 16, 50)
+        big.width, big.height = 1500, 1000
+        sbuf = np.zeros((500, 750, 3), dtype=np.uint8)
+        bbuf = np.zeros((1000, 1500, 3), dtype=np.uint8)
+        redraw, shots = [], []
+
+        def render_thread():
+            for _ in range(30):
+                t0 = time.perf_counter()
+                fr.get_image_rows(small, 0, 500, fr.Precision.F64, out=sbuf)
+                redraw.append((time.perf_counter() - t0) * 1e3)
+
+        def screenshot_thread():
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fr.get_image_rows(big, 0, 1000, fr.Precision.F64, out=bbuf)
+                shots.append((time.perf_counter() - t0) * 1e3)
+
+        th = [threading.Thread(target=render_thread), threading.Thread(target=screenshot_thread)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        redraw.sort()
+        rows["render thread (750x500) beside the screenshot thread (1500x1000), two host threads"] = {
+            "redraw_median_ms": redraw[len(redraw) // 2], "redraw_max_ms": redraw[-1], "screenshot_median_ms": sorted(shots)[1]}
+        out["mandelbrot default view" if view == "default" else "julia -0.8+0.156i (C4's view)"] = rows
+    out["note"] = ("fr_render_rows_rgb8 / fr_render_rows_rgba8 into a resident host buffer, f64, wall time of the call (kernel + D2H "
+                   "+ call overhead); first_call_ms = the first call of this process for that frame shape")
+    return out
 
 
 def run_single(args, torch, fr, lib, native):
@@ -288,9 +382,9 @@ def run_single(args, torch, fr, lib, native):
         "pixel_iterations_per_image": total,
         "kernel_ms_avg": m["kernel_ms"],
         "build_id": fr.build_id(),
-        "roofline": dict(roofline_block(args.precision, total, m["kernel_ms"], pixels,
-                                        m["kernel"] + " (fused coordinate map + orbit loop + colour map)",
-                                        traffic_record(cfg, args.precision, args.view)), note=ROOFLINE_NOTE),
+        "roofline": dict(roofline_with_pmc(roofline_block(args.precision, total, m["kernel_ms"], pixels,
+                                                          m["kernel"] + " (fused coordinate map + orbit loop + colour map)", None),
+                                           pmc_record(cfg, args.precision, args.view, fr.build_id())), note=ROOFLINE_NOTE),
     }
     if args.no_extras:
         print(json.dumps(out), flush=True)
@@ -343,10 +437,11 @@ def run_single(args, torch, fr, lib, native):
 
     # the other single-GPU BASELINE configs, driver-timed in the same run (C3 is ~1.2 s a step: 2 steps)
     if is_c2:
+        out["gui_latency"] = gui_latency(fr)
         out["other_configs"] = {
             "C3": other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1),
-            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 3),  # 3 warm-ups: one per survivor-list buffer of the ring
-            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 3),
+            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 2, cpu_compare=not args.no_cpu_baseline),
+            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2, cpu_compare=not args.no_cpu_baseline),
             "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
         }
         # C5's image (65536^2, 12.9 GB) on ONE device: what each of 8 GPUs would share out; the 8-GPU run is the driver's

@@ -165,10 +165,11 @@ def get_image_fern(config, threads=1, seed=0, walkers=0):
     return out
 
 
-def get_image_rgba(config, precision=Precision.F64):
+def get_image_rgba(config, precision=Precision.F64, out=None):
     """get_image as RGBA8 (alpha 255): uint8 [height, width, 4] — the GUI's upload format
     (src/gui.rs:71-72) produced on the device."""
-    out = np.empty((config.height, config.width, 4), dtype=np.uint8)
+    if out is None:
+        out = np.empty((config.height, config.width, 4), dtype=np.uint8)
     _native.check(
         _native.load().fr_render_rows_rgba8(C.byref(config), int(precision), 0, config.height, out.ctypes.data,
                                             out.nbytes)

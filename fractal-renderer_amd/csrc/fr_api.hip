@@ -149,6 +149,14 @@ int Ctx::create(int device) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sample_counters), 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(sample_counters, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sample_result), 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    /* every palette / claim-counter slot and every ring event now, so that no render allocates them on its way */
+    constexpr size_t kSlotWords = FR_MAX_PALETTE_ENTRIES + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&palette_block), sizeof(uint32_t) * kSlotWords * kPaletteSlots));
+    for (int k = 0; k < kPaletteSlots; k++) {
+        palette_slots[k].dev = palette_block + (size_t)k * kSlotWords;
+        HIP_TRY(hipEventCreateWithFlags(&palette_slots[k].done, hipEventDisableTiming));
+    }
+    for (SurvSlot &ss : surv_slots) HIP_TRY(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
     hip_device = device;
     return FR_OK;
 }
@@ -164,15 +172,17 @@ void Ctx::destroy() {
     {
         std::lock_guard<std::mutex> pl(palette_mu);
         for (PaletteSlot &ps : palette_slots) {
-            if (ps.dev) (void)hipFree(ps.dev);
             if (ps.done) (void)hipEventDestroy(ps.done);
             ps = PaletteSlot();
         }
+        if (palette_block) (void)hipFree(palette_block);
+        palette_block = nullptr;
         for (SurvSlot &ss : surv_slots) {
-            if (ss.dev) (void)hipFree(ss.dev);
             if (ss.done) (void)hipEventDestroy(ss.done);
             ss = SurvSlot();
         }
+        if (surv_block) (void)hipFree(surv_block);
+        surv_block = nullptr, surv_slot_cap = 0;
     }
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -231,11 +241,7 @@ int Ctx::acquire_palette(PaletteSlot **out) {
         s->pending = false;
     }
     hipError_t e = hipSuccess;
-    if (!s->dev) {
-        e = hipMalloc(reinterpret_cast<void **>(&s->dev), sizeof(uint32_t) * (FR_MAX_PALETTE_ENTRIES + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE));
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
-    }
-    if (e == hipSuccess && pending) e = hipEventSynchronize(s->done); /* blocks only if 16 renders are in flight */
+    if (pending) e = hipEventSynchronize(s->done); /* blocks only if 16 renders are in flight */
     if (e != hipSuccess) {
         {
             std::lock_guard<std::mutex> lk(palette_mu);
@@ -263,9 +269,37 @@ void Ctx::release_palette(PaletteSlot *slot, hipStream_t st) {
 
 int Ctx::acquire_surv(size_t bytes, SurvSlot **out) {
     SurvSlot *s = nullptr;
-    bool pending;
+    bool pending = false;
+    hipError_t e = hipSuccess;
     {
         std::unique_lock<std::mutex> lk(palette_mu);
+        if (surv_slot_cap < bytes) {
+            /* the ring is (re)made in one allocation: wait until nobody is between acquire and release, wait for the
+             * renders that used the old buffers, then free and allocate — the one blocking allocation of the render
+             * path (the first launch that needs lists, or one that needs larger lists than any before) */
+            slot_cv.wait(lk, [&] {
+                for (const SurvSlot &c : surv_slots)
+                    if (c.busy) return false;
+                return true;
+            });
+            if (surv_slot_cap < bytes) { /* (another thread may have grown it meanwhile) */
+                for (SurvSlot &c : surv_slots) {
+                    if (c.pending && e == hipSuccess) e = hipEventSynchronize(c.done);
+                    c.pending = false;
+                    c.dev = nullptr;
+                }
+                if (surv_block && e == hipSuccess) e = hipFree(surv_block);
+                surv_block = nullptr, surv_slot_cap = 0;
+                const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+                if (e == hipSuccess) e = hipMalloc(&surv_block, cap * kSurvSlots);
+                if (e != hipSuccess) {
+                    surv_block = nullptr;
+                    return fail_hip(e, "survivor-list ring");
+                }
+                surv_slot_cap = cap;
+                for (int k = 0; k < kSurvSlots; k++) surv_slots[k].dev = static_cast<char *>(surv_block) + (size_t)k * cap;
+            }
+        }
         while (!s) {
             for (int tries = 0; tries < kSurvSlots && !s; tries++) {
                 SurvSlot &c = surv_slots[surv_next++ % kSurvSlots];
@@ -277,21 +311,13 @@ int Ctx::acquire_surv(size_t bytes, SurvSlot **out) {
         pending = s->pending;
         s->pending = false;
     }
-    hipError_t e = hipSuccess;
-    if (!s->done) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
-    if (e == hipSuccess && pending) e = hipEventSynchronize(s->done); /* the buffer's previous render */
-    if (e == hipSuccess && s->cap < bytes) {
-        if (s->dev) e = hipFree(s->dev);
-        s->dev = nullptr, s->cap = 0;
-        if (e == hipSuccess) e = hipMalloc(&s->dev, bytes);
-        if (e == hipSuccess) s->cap = bytes;
-    }
+    if (pending) e = hipEventSynchronize(s->done); /* the buffer's previous render (three are in flight) */
     if (e != hipSuccess) {
         {
             std::lock_guard<std::mutex> lk(palette_mu);
             s->busy = false;
         }
-        slot_cv.notify_one();
+        slot_cv.notify_all();
         return fail_hip(e, "survivor-list buffer");
     }
     *out = s;
@@ -307,7 +333,7 @@ void Ctx::release_surv(SurvSlot *slot, hipStream_t st) {
         slot->pending = recorded;
         slot->busy = false;
     }
-    slot_cv.notify_one();
+    slot_cv.notify_all();
 }
 
 namespace {
@@ -625,10 +651,10 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
     }
     SurvSlot *surv = nullptr;
     if (want_lists) {
-        /* room for a quarter of the pixels (C4 leaves a tenth); what does not fit is finished by the first
-         * pass itself, so the size is a matter of speed only */
+        /* room for an eighth of the pixels (C4 hands over one in fifteen; the views of tools/two_pass_views.py at most
+         * one in twelve); what does not fit is finished by the first pass itself, so the size is a matter of speed only */
         const uint64_t npix = (uint64_t)p.ncols * p.nrows;
-        uint64_t entries = npix / 4;
+        uint64_t entries = npix / 8;
         if (entries < 65536) entries = 65536;
         if (entries > (256ull << 20)) entries = 256ull << 20;
         uint64_t sub = (entries + FR_SURV_QUEUES - 1) / FR_SURV_QUEUES;

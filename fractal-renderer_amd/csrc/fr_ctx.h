@@ -66,11 +66,12 @@ struct PaletteSlot {
 };
 constexpr int kPaletteSlots = 16;
 
-/* Survivor lists of the two-pass render (fr_kernels.hip): a ring of three device buffers, grown on demand,
- * handed out like the palette slots. */
+/* Survivor lists of the two-pass render (fr_kernels.hip): a ring of three buffers cut from ONE device allocation
+ * (Ctx::surv_block), made when the first launch that needs lists arrives and re-made only for a launch that needs more
+ * than a slot holds — the one allocation the device-pointer entry points can block on (first large two-pass frame,
+ * or a larger one than any before); handed out like the palette slots. */
 struct SurvSlot {
     void *dev = nullptr;
-    size_t cap = 0;
     hipEvent_t done = nullptr;
     bool pending = false, busy = false;
 };
@@ -86,6 +87,9 @@ struct Ctx {
     Scratch rgb, z, iters, misc;
     PaletteSlot palette_slots[kPaletteSlots];
     SurvSlot surv_slots[kSurvSlots];
+    void *surv_block = nullptr; /* kSurvSlots x surv_slot_cap bytes */
+    size_t surv_slot_cap = 0;
+    uint32_t *palette_block = nullptr; /* kPaletteSlots slots, allocated with the context */
     /* view sample (fr_api.hip: choose_kernel): a stream of its own — the sample must not wait behind whatever the
      * caller has queued on its stream — five device counters, four host-mapped result words, a few remembered views */
     hipStream_t aux_stream = nullptr;

@@ -323,8 +323,12 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
  *      dozen iterations and colour what has escaped, tile by tile; a tile whose running lanes fall under a
  *      threshold hands them — position, iterations done, output position — to lists in device memory, which the
  *      work-queue kernel's persistent waves then finish.  Same conditions as 10 (otherwise it acts as 9).  The
- *      lists live in a context-owned scratch buffer of 20-36 bytes per entry, one entry per four pixels of the
- *      launch (at most 2^28 entries); a list that is full costs speed only;
+ *      lists live in a context-owned ring of three buffers cut from one allocation: per entry 20 bytes (f32 Julia),
+ *      28 (f64 Julia; f32 Mandelbrot), 44 (f64 Mandelbrot), one entry per eight pixels of the launch (at most 2^28
+ *      entries) — C4 in f32: 671 MB per buffer, 2 GB for the ring.  The ring is allocated when the first launch that
+ *      needs lists arrives and re-allocated only for a launch that needs more: the one allocation a device-pointer
+ *      render can block on (~15 ms, once).  A list that is full costs speed only;
+ * 13 = that first pass alone: no tile is handed over (every lane finishes in place), no lists, no second kernel;
  * 6401, 3202, 1604, 808 = the 4-wave-workgroup kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave
  * pixel footprint. */
 int fr_set_tile(int tile);

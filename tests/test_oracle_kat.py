@@ -203,3 +203,41 @@ def test_oracle_soft_log2_is_a_verbatim_copy():
     assert "fractal-renderer_amd" not in mk.replace("# ", ""), "oracle/Makefile must not reach into the product tree"
     src = open(os.path.join(root, "oracle", "fractal_oracle.c")).read()
     assert '#include "../' not in src
+
+
+def test_reference_screenshot_agrees_with_the_oracles_channel_order_and_inside_rule():
+    """VERDICT r02 #7.  The reference holds no test vectors; its one output artefact is a lossy, rescaled AVIF whose
+    parameters are unrecorded (README.md:9-11).  tests/golden/make_screenshot_stats.py reduced it to channel statistics.
+    This is a CONSISTENCY check on SURVEY §8 row a6 — not a pin; parity stays "unpinned":
+      * exterior pixels of the screenshot are blue-dominant with R ~ G and B/R ~ 255/40: RGB::new(40, 40, 255) through
+        color_multiply's g/b swap emits (40m, 40m, 255m) (calc/src/lib.rs:129-139) — what the oracle emits;
+      * a quarter of the screenshot is black: `inside = false` renders the set's interior BLACK (calc/src/lib.rs:233) —
+        what the oracle does with the same flag;
+      * an oracle render of a deep view with -d shows the same two facts exactly."""
+    import json
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    st = json.load(open(os.path.join(here, "golden", "reference_screenshot_stats.json")))
+    assert (st["width"], st["height"]) == (1000, 1000)
+    want_ratio = 255.0 / 40.0
+    assert abs(st["b_over_r_median"] - want_ratio) / want_ratio < 0.05, st          # 6.4 against 6.375, through a lossy codec
+    assert st["b_over_r_p10"] > 5.0 and st["b_over_r_p90"] < 7.5, st
+    assert abs(st["r_minus_g_median"]) <= 1.0 and st["abs_r_minus_g_p90"] <= 4.0, st  # R ~ G
+    assert st["fraction_green_above_blue"] == 0.0, st                              # blue, never green
+    assert st["black_fraction"] > 0.1, st                                          # -d: the interior is black
+    # the oracle, same colours, inside off, a zoomed view with both interior and exterior
+    cfg = O.cli_config(200, 200, O.MANDELBROT, iterations=500, pos=(-0.7436447860, 0.1318252536), scale=(3000.0, 3000.0), inside=False)
+    img = O.get_image(cfg).astype(np.int64)
+    z, iters = O.escape_rows(cfg)
+    z = z.reshape(200, 200, 2)
+    # "inside" in the reference's sense: the orbit ended within stable_limit of the origin (calc/src/lib.rs:216; a bounded
+    # orbit that ends further out is coloured as outside, KAT-3)
+    inside = (z[..., 0] ** 2 + z[..., 1] ** 2) <= cfg.stable_limit
+    assert inside.any() and (~inside).any()
+    assert (img[inside] == 0).all()                                                # interior: BLACK
+    R, G, B = img[..., 0], img[..., 1], img[..., 2]
+    assert (R == G).all()                                                          # 40 m and 40 m, truncated alike
+    meas = (~inside) & (R >= 16) & (B < 250)
+    ratio = B[meas] / R[meas]
+    assert meas.sum() > 100 and abs(np.median(ratio) - want_ratio) / want_ratio < 0.03
