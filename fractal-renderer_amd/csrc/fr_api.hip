@@ -660,6 +660,9 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
         uint64_t sub = (entries + FR_SURV_QUEUES - 1) / FR_SURV_QUEUES;
         if (const uint32_t forced = g_two_pass_list_entries.load()) sub = forced;
         sub = (sub + FR_SURV_CHUNK - 1) / FR_SURV_CHUNK * FR_SURV_CHUNK;
+        /* the 64 lists fill at about the same rate: keep their write heads off a common power-of-two stride (the same
+         * memory channel for all of them) */
+        if ((sub & 4095u) == 0 && !g_two_pass_list_entries.load()) sub += 3 * FR_SURV_CHUNK;
         p.surv_sub_capacity = (uint32_t)sub;
         const fr_two_pass_layout lay = fr_two_pass_bytes(p, precision, p.surv_sub_capacity);
         int rc = ctx.acquire_surv(lay.total, &surv);

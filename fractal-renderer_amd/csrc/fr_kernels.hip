@@ -1232,12 +1232,42 @@ __device__ __forceinline__ bool lane_in(unsigned long long m) {
     "s_mov_b64 %[srun], exec\n"                        \
     "s_mov_b64 exec, %[sorig]\n"
 
+/* the same loop with the count kept per lane (27 vector instructions per block, 3 scalar): f32 renders, whose scalar
+ * unit is the co-limiter (C4-f32 with the handler form in its later episodes: +4 %) */
+#define FR_FBC_ASM(SFX, BLOCK_ITS, STEP)               \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    "s_mov_b64 exec, %[mask]\n"                        \
+    ".Lfc_%=:\n" BLOCK_ITS                             \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_cbranch_execz .Lfcd_%=\n"                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc0 .Lfc_%=\n"                         \
+    ".Lfcd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"
+
 template <typename T, int M>
 __device__ __forceinline__ unsigned long long first_blocks(unsigned long long mask, uint32_t nblocks, uint32_t done_before, T &X, T &Y,
                                                            T &A, T &B, T &t, float &cnt, T c2re, T c2im,
                                                            typename UBits<T>::type t4lim) {
     T q;
     unsigned long long sorig, srun, sprev, sdiff;
+    if constexpr (sizeof(T) == 4) {
+        uint32_t kc = __builtin_amdgcn_readfirstlane(nblocks) - 1u;
+        (void)done_before, (void)sprev, (void)sdiff;
+#define FR_FBC_OPERANDS                                                                                          \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),            \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(kc)                                                     \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask)                                   \
+    : "vcc", "scc"
+        if constexpr (M == 4)
+            asm volatile(FR_FBC_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_FBC_OPERANDS);
+        else
+            asm volatile(FR_FBC_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_FBC_OPERANDS);
+        return srun;
+    }
     const uint32_t n0 = __builtin_amdgcn_readfirstlane(nblocks), base = __builtin_amdgcn_readfirstlane(done_before);
     uint32_t k = n0 - 1u, stmp;
 #define FR_FB_OPERANDS                                                                                           \
@@ -1251,11 +1281,6 @@ __device__ __forceinline__ unsigned long long first_blocks(unsigned long long ma
             asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "2") FR_FB_OPERANDS);
         else
             asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "1") FR_FB_OPERANDS);
-    } else {
-        if constexpr (M == 4)
-            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "2") FR_FB_OPERANDS);
-        else
-            asm volatile(FR_FB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "1") FR_FB_OPERANDS);
     }
     return srun;
 }
@@ -1612,9 +1637,9 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                 unsigned long long handed = 0ull;
                 if (st != 3u) {
                     /* episodes of k1 iterations for as long as the tile is worth a wave of its own — at least `keep`
-                     * lanes still running; a tile still here after two episodes is most likely inside a filled set: from
-                     * then on every episode is twice the last, up to 16 x k1 (a tile that thins out in mid-episode idles
-                     * for at most as long as it has already run; 1024 iterations take 5 episodes instead of 11) */
+                     * lanes still running; a tile still here after 8 episodes is most likely inside a filled set: from
+                     * then on every episode is twice the last, up to 16 x k1 (doubling from the third episode on was
+                     * tried: C4's dense tiles thin out within an episode or two and idled through the longer ones) */
                     uint32_t len = k1;
                     bool first = st == 1u; /* the asm path has run the first episode */
                     while (run != 0ull) {
@@ -1630,7 +1655,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                         }
                         if (run == 0ull || cap - done < (uint32_t)M) break;
                         if ((uint32_t)__builtin_popcountll(run) < keep) break;
-                        if (done >= 2u * k1 && len < 16u * k1) len += len;
+                        if (done >= 8u * k1 && len < 16u * k1) len += len;
                     }
                     if (st == 1u && done == 0u) done = k1;
                     /* lanes that ran through those episodes carry no count of their own (first_blocks): it is `done` */
@@ -2790,7 +2815,7 @@ __global__ __launch_bounds__(64) void view_sample_kernel(const fr_kparams p, uin
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
     const unsigned long long capped = (unsigned long long)__builtin_popcountll(__ballot(valid && executed == cap_s));
     /* what the two-pass render would do with this tile: episodes (the first pass's own schedule: `episode` iterations,
-     * doubling from the third on, up to 16 x) for as long as at least `keep` lanes are still running; at the first
+     * doubling from the ninth on, up to 16 x) for as long as at least `keep` lanes are still running; at the first
      * boundary where fewer are, it hands them over.  Finishing them in place instead costs the wave (longest - boundary)
      * more iterations, of which only the running lanes' own are useful */
     uint32_t e = episode, len = episode, nrun = 0;
@@ -2801,7 +2826,7 @@ __global__ __launch_bounds__(64) void view_sample_kernel(const fr_kparams p, uin
             hands_over = nrun > 0u;
             break;
         }
-        if (e >= 2u * episode && len < 16u * episode) len += len;
+        if (e >= 8u * episode && len < 16u * episode) len += len;
         e += len;
     }
     unsigned long long rest = executed > e ? executed - e : 0u;
