@@ -448,6 +448,7 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
     const double ak = std::fabs(p.filt_k);
     p.colour_filter32 = (filter_ok && o.colour_filter == 1 && n < (1u << 24) && ak >= 0x1p-60 && ak <= 0x1p60) ? 1u : 0u;
     p.filt_k32 = (float)p.filt_k;
+    p.filt_c32 = p.colour_filter32 ? std::nextafterf((float)(ak * FR_NU_BRACKET * (1.0 + 0x1p-9)), INFINITY) : 0.0f;
     for (int k = 0; k < 3; k++) {
         p.filt_d[k] = p.prim_f[k] * ak * FR_NU_BRACKET * (1.0 + 0x1p-20);
         p.filt_d32[k] = p.colour_filter32 ? std::nextafterf((float)(p.prim_f[k] * ak * FR_NU_BRACKET * (1.0 + 0x1p-10)), INFINITY) : 0.0f;

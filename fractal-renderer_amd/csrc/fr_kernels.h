@@ -68,6 +68,8 @@ struct fr_kparams {
     /* the filter's f32 first stage: on only when iterations < 2^24 and 2^-60 <= |filt_k| <= 2^60 */
     uint32_t colour_filter32;
     float filt_k32;    /* (float)filt_k */
+    float filt_c32;    /* |filt_k| * FR_NU_BRACKET * (1 + 2^-9), rounded up: the bracket's half-width per unit of colour field
+                        * (field * filt_c32 >= filt_d32[field's index]); the first pass's form of the f32 stage */
     float filt_d32[3]; /* the same half-widths, times (1 + 2^-10), rounded up to f32 */
     float prim32[3];   /* the stored colour fields as f32 (exact) */
     /* f32 renders: max(stable_limit, 2) * (1 + 2^-20) rounded up — an f32 squared distance at or above it proves

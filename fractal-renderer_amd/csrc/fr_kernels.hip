@@ -1345,7 +1345,7 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
 #define FR_TILE_ASM(SFX, MOVT, REST_ITS, STEP)         \
     "s_load_dwordx2 %[fa], %[kargs], %[offa]\n"        \
     "s_load_dwordx2 %[fb], %[kargs], %[offb]\n"        \
-    "s_load_dword %[fk], %[kargs], %[offk]\n"          \
+    "s_load_dwordx2 %[fk], %[kargs], %[offk]\n"        \
     "v_add_" SFX " %[X], %[sre], %[sre]\n"             \
     "v_mul_" SFX " %[A], %[X], %[X]\n"                 \
     "v_add_" SFX " %[t], %[A], %[B0]\n"                \
@@ -1407,9 +1407,10 @@ __device__ __forceinline__ unsigned long long finish_scaled(unsigned long long m
 template <typename T, int M>
 __device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, T c2re, T c2im, typename UBits<T>::type t4lim,
                                               typename UBits<T>::type lim4, KArgs kargs, T &X, T &Y, T &A, T &B, T &t, float &cnt,
-                                              unsigned long long &srun, unsigned long long &fa, unsigned long long &fb, uint32_t &fk) {
-    static_assert(offsetof(fr_kparams, filt_lo32) == offsetof(fr_kparams, prim32) + 12 && offsetof(fr_kparams, prim32) % 4 == 0,
-                  "prim32[0..1] | prim32[2], filt_lo32: two 8-byte loads");
+                                              unsigned long long &srun, unsigned long long &fa, unsigned long long &fb, unsigned long long &fk) {
+    static_assert(offsetof(fr_kparams, filt_lo32) == offsetof(fr_kparams, prim32) + 12 && offsetof(fr_kparams, prim32) % 4 == 0 &&
+                      offsetof(fr_kparams, filt_c32) == offsetof(fr_kparams, filt_k32) + 4,
+                  "prim32[0..1] | prim32[2], filt_lo32 | filt_k32, filt_c32: three 8-byte loads");
     T q;
     unsigned long long sorig;
     uint32_t st, k = nblk - 1u;
@@ -1436,21 +1437,37 @@ __device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, 
     return st;
 }
 
-/* the filter's first stage with its constants held by the caller (scalar registers, loaded once per workgroup) */
+/* The filter's first stage as the first pass evaluates it (same test, fewer instructions; constants fetched by
+ * tile_fast).  The three channels are p_k * m with ONE m, and the window of channel k is p_k * w with
+ *     w = |m| * 2^-20 + c,      c = |K| * E * (1 + 2^-9) rounded up     (p_k * c >= filt_d32[k], p_k >= 0),
+ * so both ends of all three windows come from two numbers, m - w and m + w.  The relative part is 2^-20 where
+ * colour_filter_stage1 has 2^-21: the ends here carry two more roundings (m -/+ w, then the fma), 2^-24 each, on
+ * top of the 2.4e-7 of m itself — 3.6e-7 against a window of 9.5e-7.  And the truncating cast of an end x is
+ * v_cvt_pk_u8_f32(x - 0.5), the -0.5 folded into the fma: round-to-nearest-even of x - 0.5 IS floor(x) unless x is
+ * an exact integer, where it may give x - 1; at the lower end that can only turn "decided" into "undecided", and at
+ * the upper end x - 1 is the right answer, because the true value lies STRICTLY inside the window (the slack above).
+ * Saturation and NaN as in sat_u8_pack.  Returns whether the byte triple is decided (then `lo` holds it). */
 struct Filter32 {
-    float lo, k, p0, p1, p2; /* scalars; channels in OUTPUT order (color_multiply's swap applied where this is filled) */
-    float d0, d1, d2;        /* held per lane: a VOP3 takes ONE scalar operand, and the fma's 2^-21 is one already */
+    float lo, k, c, p0, p1, p2; /* channels in OUTPUT order (color_multiply's swap applied where this is filled) */
 };
+__device__ __forceinline__ uint32_t cvt_pk_u8_at(float v, uint32_t acc, int K) {
+    uint32_t u;
+    if (K == 0)
+        asm("v_cvt_pk_u8_f32 %0, %1, 0, %2" : "=v"(u) : "v"(v), "v"(acc));
+    else if (K == 1)
+        asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(u) : "v"(v), "v"(acc));
+    else
+        asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(u) : "v"(v), "v"(acc));
+    return u;
+}
 __device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, float itp1, uint32_t &lo) {
     const float l1 = __builtin_amdgcn_logf(d32);
     const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
-    const float m32 = (itp1 - nu32) * f.k;
-    const float v0 = f.p0 * m32, v1 = f.p1 * m32, v2 = f.p2 * m32;
-    const float w0 = __builtin_fmaf(__builtin_fabsf(v0), 0x1p-21f, f.d0);
-    const float w1 = __builtin_fmaf(__builtin_fabsf(v1), 0x1p-21f, f.d1);
-    const float w2 = __builtin_fmaf(__builtin_fabsf(v2), 0x1p-21f, f.d2);
-    lo = sat_u8_pack<2>(v2 - w2, sat_u8_pack<1>(v1 - w1, sat_u8_pack<0>(v0 - w0, 0u)));
-    const uint32_t hi = sat_u8_pack<2>(v2 + w2, sat_u8_pack<1>(v1 + w1, sat_u8_pack<0>(v0 + w0, 0u)));
+    const float m = (itp1 - nu32) * f.k;
+    const float w = __builtin_fmaf(__builtin_fabsf(m), 0x1p-20f, f.c);
+    const float ml = m - w, mh = m + w;
+    lo = cvt_pk_u8_at(__builtin_fmaf(f.p2, ml, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p1, ml, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p0, ml, -0.5f), 0u, 0), 1), 2);
+    const uint32_t hi = cvt_pk_u8_at(__builtin_fmaf(f.p2, mh, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p1, mh, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p0, mh, -0.5f), 0u, 0), 1), 2);
     return lo == hi;
 }
 
@@ -1494,7 +1511,6 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     bool cols_scalable;
     unsigned long long bad_rows;
     bool narrow;
-    float fd0, fd1, fd2; /* the filter's three half-widths in output-channel order, one copy per lane (see Filter32) */
     bool fast_colour; /* the f32 stage of the colour filter applies to this render (wave-uniform, per launch) */
     {
         FR_COLD_PARAMS(kp);
@@ -1534,8 +1550,6 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
         bad_rows = __ballot(row_relevant && !coord_is_scalable<T>(is_julia, rows));
         /* colour_multiply's RGB::new(r, b, g) swap (calc/src/lib.rs:129-139): output channel k takes field {0, 2, 1}[k] */
         fast_colour = P.colour_filter32 && P.smooth && P.palette == nullptr;
-        fd0 = P.filt_d32[0], fd1 = P.filt_d32[2], fd2 = P.filt_d32[1];
-        asm volatile("" : "+v"(fd0), "+v"(fd1), "+v"(fd2)); /* vector registers from here on */
     }
     /* the host guarantees 0 < k1 < cap < 2^24; first_only: no tile is ever handed over (keep = 0), every lane finishes here */
     const uint32_t k1 = p.first_cap, cap = p.iterations, keep = p.first_only ? 0u : p.first_keep;
@@ -1597,16 +1611,15 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                  * the loads' latency, instead of being held in scalar registers across the workgroup (they were
                  * spilled to vector lanes and every tile paid 16 v_readlane — vector-issue slots — to get them back):
                  * tile_fast issues the two loads before its loops and waits for them behind them */
-                unsigned long long fa, fb;
-                uint32_t fk;
+                unsigned long long fa, fb, fk;
                 st = tile_fast<T, M>(nblk1, sre, Y0, B0, c2re, c2im, t4lim, lim4, (KArgs)__builtin_amdgcn_kernarg_segment_ptr(), X, Y, A,
                                      B, t, cnt, run, fa, fb, fk);
                 Filter32 fc;
-                fc.lo = __builtin_bit_cast(float, (uint32_t)(fb >> 32)), fc.k = __builtin_bit_cast(float, fk);
+                fc.lo = __builtin_bit_cast(float, (uint32_t)(fb >> 32));
+                fc.k = __builtin_bit_cast(float, (uint32_t)fk), fc.c = __builtin_bit_cast(float, (uint32_t)(fk >> 32));
                 /* colour_multiply's RGB::new(r, b, g) swap: output channel k takes stored field {0, 2, 1}[k] */
                 fc.p0 = __builtin_bit_cast(float, (uint32_t)fa), fc.p1 = __builtin_bit_cast(float, (uint32_t)fb);
                 fc.p2 = __builtin_bit_cast(float, (uint32_t)(fa >> 32));
-                fc.d0 = fd0, fc.d1 = fd1, fc.d2 = fd2;
                 /* The common case to its end, apart from everything else (no state shared with the general path
                  * below, so nothing is merged or copied for it): every lane escaped, and the filter's first stage
                  * decides every lane's bytes from the f32 squared distance — (A + B) / 4 IS fl(re^2 + im^2), see
@@ -1720,9 +1733,8 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                 Filter32 f32c;
                 {
                     FR_COLD_PARAMS(kp);
-                    f32c.lo = kp->filt_lo32, f32c.k = kp->filt_k32;
+                    f32c.lo = kp->filt_lo32, f32c.k = kp->filt_k32, f32c.c = kp->filt_c32;
                     f32c.p0 = kp->prim32[0], f32c.p1 = kp->prim32[2], f32c.p2 = kp->prim32[1];
-                    f32c.d0 = fd0, f32c.d1 = fd1, f32c.d2 = fd2;
                 }
                 const bool unsure = !(d32 >= f32c.lo && d32 <= 0x1.ffffep119f);
                 if ((__ballot(unsure) & fin) == 0ull) {
