@@ -109,11 +109,8 @@ __device__ __forceinline__ uint32_t sat_u8_dev(float v) { /* the same, from an f
  * of a pixel arrive packed. */
 template <int K>
 __device__ __forceinline__ uint32_t sat_u8_pack(float v, uint32_t acc) {
-    float f;
-    uint32_t u;
-    asm("v_floor_f32 %0, %1" : "=v"(f) : "v"(v));
-    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(u) : "v"(f), "n"(K), "v"(acc));
-    return u;
+    /* the compiler's own v_floor_f32 / v_cvt_pk_u8_f32 (inline asm here drew an s_nop before every dependent use) */
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(v), (uint32_t)K, acc);
 }
 
 __device__ __forceinline__ void colour_multiply(const double col[3], double mult, uint8_t out[3]) {
@@ -1451,14 +1448,7 @@ struct Filter32 {
     float lo, k, c, p0, p1, p2; /* channels in OUTPUT order (color_multiply's swap applied where this is filled) */
 };
 __device__ __forceinline__ uint32_t cvt_pk_u8_at(float v, uint32_t acc, int K) {
-    uint32_t u;
-    if (K == 0)
-        asm("v_cvt_pk_u8_f32 %0, %1, 0, %2" : "=v"(u) : "v"(v), "v"(acc));
-    else if (K == 1)
-        asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(u) : "v"(v), "v"(acc));
-    else
-        asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(u) : "v"(v), "v"(acc));
-    return u;
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, (uint32_t)K, acc); /* v_cvt_pk_u8_f32 (the builtin: no s_nop padding around it, as inline asm gets) */
 }
 __device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, float itp1, uint32_t &lo) {
     const float l1 = __builtin_amdgcn_logf(d32);
