@@ -549,7 +549,7 @@ std::atomic<int> g_dispatch_sampling{1};
  *             share of the work — what the two-pass render's lists exist to save;
  *   mean      executed iterations per pixel (x pixels / the first pass's rate = an estimate of the render's time).
  * Three kernels (measured on 13 views x 2 precisions, tools/two_pass_views.py, profiles/r03_kernel_choice_views.txt):
- *   two passes        pay ~40 us for their lists and second kernel; taken when the waste they save is worth more;
+ *   two passes        taken when the first pass's schedule would hand over at least one pixel in 500;
  *   first pass alone  (7-tile strips in episodes, frozen lanes finished once per tile, nothing handed over): 10-13 % ahead
  *                     of the strip kernel on views of short orbits, level with it on long ones;
  *   strips            1-3 % ahead on interior-heavy views (its loop is 6.5 vector instructions per iteration from the first).
@@ -573,7 +573,7 @@ static uint64_t view_key(const fr_config *cfg, const fr_kparams &p, int precisio
     return h ? h : 1;
 }
 
-int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[6]) {
+int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[7]) {
     std::lock_guard<std::mutex> lk(ctx.sample_mu);
     void *d_result = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_result, ctx.sample_result, 0));
@@ -581,7 +581,7 @@ int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[6]) {
     HIP_TRY(fr_launch_view_sample(p, precision, 16, cap_s, 64, 48, ctx.sample_counters, static_cast<unsigned long long *>(d_result),
                                   ctx.aux_stream));
     HIP_TRY(hipStreamSynchronize(ctx.aux_stream));
-    for (int k = 0; k < 6; k++) out[k] = (double)__atomic_load_n(ctx.sample_result + k, __ATOMIC_RELAXED);
+    for (int k = 0; k < 7; k++) out[k] = (double)__atomic_load_n(ctx.sample_result + k, __ATOMIC_RELAXED);
     return FR_OK;
 }
 
@@ -601,19 +601,19 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
                 return v.two_pass;
             }
     }
-    double st[6];
+    double st[7];
     if (sample_view(ctx, p, precision, st) != FR_OK || st[1] <= 0.0) return -1; /* no opinion rather than a failed render */
     const double lanes = 64.0 * st[2];
-    const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes;
-    /* the render's time, roughly: the first pass runs ~4.5e12 (f32) / 3e12 (f64) pixel-iterations a second */
-    const double est_us = mean * (double)p.ncols * (double)p.nrows / (precision == FR_PRECISION_F32 ? 4.5e6 : 3.0e6);
+    const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes, handed = st[4] / lanes;
     int choice;
     if (capped >= 0.10 && waste < 0.01)
         choice = 0; /* long orbits dominate and tiles stay full: the strip kernel's ground */
-    else if (waste * est_us >= 400.0)
-        choice = 1; /* stragglers worth more than the lists cost: the second pass recovers about a fifth of the idled
-                     * lane-time (it is itself 47 lanes of 64 busy, at twice the first pass's cost per iteration), and its
-                     * lists, memsets and second kernel cost ~80 us whatever it finds */
+    else if (handed >= 0.002 || (handed * (double)p.ncols * (double)p.nrows >= 4096.0 && st[6] >= 128.0 * st[4]))
+        choice = 1; /* thinned-out tiles would hand over at least one pixel in 500 — or fewer, but thousands of them with long
+                     * tails (128 iterations and more to go, on average): finished in place those are a few workgroups' serial
+                     * chains, in the lists they spread over the chip — the lists pay (measured from 131 072-tile
+                     * launches up; an estimate of the idle time saved against the second pass's cost was tried as the
+                     * criterion and mispredicted wide launches, whose second pass costs next to nothing) */
     else
         choice = 2;
     std::lock_guard<std::mutex> lk(ctx.sample_mu);
@@ -1268,7 +1268,8 @@ int fr_set_dispatch_sampling(int enabled) {
 
 /* what choose_kernel measures, for tools and tests: out[0..5] = executed iterations, 64 x sum of per-tile maxima, tiles
  * sampled, lanes at the sample's cap (1024), lanes handed over after a 64-iteration episode (keep 48), lane-iterations
- * wasted by finishing those in place; out[6] = out[0] / out[1], the useful-lane fraction of one tile per wave */
+ * wasted by finishing those in place; out[6] = out[0] / out[1], the useful-lane fraction of one tile per wave; out[7] =
+ * iterations the handed-over lanes still have to run */
 int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]) {
     if (!cfg || !out) return fail(FR_ERR_INVALID_ARGUMENT, "cfg or out is NULL");
     int rc = check_precision(precision);
@@ -1283,10 +1284,12 @@ int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]) {
     p.block_rows = cfg->height ? cfg->height : 1;
     p.y_stride = 0;
     if (p.ncols == 0 || p.nrows == 0) return fail(FR_ERR_INVALID_ARGUMENT, "empty image");
-    rc = sample_view(*ctx, p, precision, out);
+    double st[7];
+    rc = sample_view(*ctx, p, precision, st);
     if (rc != FR_OK) return rc;
-    out[6] = out[1] > 0.0 ? out[0] / out[1] : 0.0;
-    out[7] = 0.0;
+    for (int k = 0; k < 6; k++) out[k] = st[k];
+    out[6] = st[1] > 0.0 ? st[0] / st[1] : 0.0;
+    out[7] = st[6];
     return FR_OK;
 }
 

@@ -2841,12 +2841,13 @@ __global__ __launch_bounds__(64) void view_sample_kernel(const fr_kparams p, uin
         if (hands_over) {
             atomicAdd(counters + 4, (unsigned long long)nrun);
             atomicAdd(counters + 5, 64ull * (mx - e) - rest); /* lane-iterations wasted by finishing in place */
+            atomicAdd(counters + 6, rest);                    /* iterations the handed-over lanes still have to run */
         }
         __threadfence();
         const unsigned long long done = atomicAdd(counters + 7, 1ull);
         if (done + 1ull == (unsigned long long)gridDim.x) { /* the last wave: publish, reset */
             __threadfence();
-            for (int k = 0; k < 6; k++) {
+            for (int k = 0; k < 7; k++) {
                 const unsigned long long v = atomicExch(counters + k, 0ull);
                 __hip_atomic_store(result + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }

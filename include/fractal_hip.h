@@ -343,7 +343,7 @@ int fr_set_dispatch_sampling(int enabled);
 /* Tool / test hook: the sample of the whole image. out[0..5] = executed iterations, 64 x the sum of the tiles' longest
  * orbits, tiles, lanes at the sample's cap of 1024, lanes the two-pass render would hand over after its first episode,
  * lane-iterations that finishing those in place would waste; out[6] = out[0] / out[1], the useful-lane fraction of
- * one-tile-per-wave rendering; out[7] = 0. */
+ * one-tile-per-wave rendering; out[7] = iterations the handed-over lanes would still have to run. */
 int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]);
 
 /* Policy of the lane-refilling kernels (tuning studies): an orbit episode may end early, so that
