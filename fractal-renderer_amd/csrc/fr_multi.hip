@@ -227,10 +227,14 @@ std::vector<std::pair<uint32_t, uint32_t>> chunk_schedule(uint32_t nb) {
 enum class Sink { Host, PeerCopy, Rccl };
 
 /* Host sink: the caller's buffer is made DMA-able in page-aligned 64 MiB chunks, front to back (every device's
- * blocks advance through the image together), by a small pool of threads — hipHostRegister of touched memory
- * takes ~0.9 ms per 64 MiB on one thread (72 GB/s: 1.3 PCIe links' worth; tools/ubench/host_path.hip measures
- * how it scales with threads) — while the devices render.  Device threads sleep on a condition variable until
- * the chunks under their block are pinned. */
+ * blocks advance through the image together), by a background thread while the devices render; device threads sleep
+ * on a condition variable until the chunks under their block are pinned.  What pinning costs was measured
+ * (tools/ubench/host_path.hip, profiles/r03_host_register_scaling.txt): hipHostRegister does NOT scale with calling
+ * threads — memory the caller touched with 4-KiB pages pins at 42 GB/s from one thread and 32-36 GB/s from 2-8 (the
+ * kernel's mm lock) — but memory backed by huge pages, which is what this library's own first touch produces for a
+ * buffer whose pages do not exist yet (a fresh Vec: fr_host.hip), pins at 430-550 GB/s whatever the chunk size or
+ * thread count, and memory that was registered before re-registers for next to nothing.  Hence ONE pinning thread
+ * (FR_PIN_THREADS overrides), and fr_pin_host_buffer for callers that keep a buffer. */
 struct PinProgress {
     ChunkPinner pinner;
     std::mutex m;
@@ -245,7 +249,7 @@ struct PinProgress {
         static const int n = [] {
             const char *e = getenv("FR_PIN_THREADS");
             if (e && atoi(e) > 0) return atoi(e) > 16 ? 16 : atoi(e);
-            return 4;
+            return 1;
         }();
         return n;
     }
