@@ -14,6 +14,7 @@ import datetime
 import glob
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +30,9 @@ for arg in sys.argv[1:]:
     kernels = set()
     for line in open(os.path.join(d, "summary.txt")):
         parts = [p.strip() for p in line.rsplit(",", 3)]
-        if len(parts) == 4 and parts[1].isupper() and ("escape_" in parts[0]) and "refill" not in parts[0] and "_v1_" not in parts[0]:
+        # render kernels only: not bench.py's one COUNT-mode launch (escape_strip_kernel<T, 2, K> / the refill kernel)
+        if (len(parts) == 4 and parts[1].isupper() and ("escape_" in parts[0]) and "refill" not in parts[0] and "_v1_" not in parts[0]
+                and not re.search(r"escape_strip_kernel<\w+, [12],", parts[0])):
             try:
                 counters[parts[1]] = counters.get(parts[1], 0.0) + float(parts[3])
                 kernels.add(parts[0].split("(anonymous namespace)::")[-1].split("(")[0])
