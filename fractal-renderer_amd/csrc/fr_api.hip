@@ -625,6 +625,20 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
     return choice;
 }
 
+void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o) {
+    if (o.tile != 0 || o.kernel_hint != -2 || y1 <= y0 || cfg->width == 0) return;
+    fr_kparams p;
+    fill_params(cfg, o, p);
+    p.nrows = y1 - y0;
+    p.y_first = y0;
+    p.block_rows = p.nrows;
+    p.y_stride = 0;
+    plan_loop(cfg, precision, o, p);
+    bool one_band = false;
+    o.kernel_hint = choose_kernel(ctx, cfg, p, precision, o, &one_band);
+    o.one_band = one_band;
+}
+
 /* device-pointer render of an arbitrary local grid; no host synchronisation, no shared scratch except
  * the palette slot `ctx` lends: re-entrant */
 int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, const Opts &o, void *d_out,
@@ -636,8 +650,8 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
     const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 13;
-    bool one_band = false;
-    const int hint = choose_kernel(ctx, cfg, p, precision, o, &one_band);
+    bool one_band = o.one_band;
+    const int hint = o.kernel_hint != -2 ? o.kernel_hint : choose_kernel(ctx, cfg, p, precision, o, &one_band);
     const bool want_two_pass = fr_wants_two_pass(p, precision, o.tile, hint);
     p.first_one_band = one_band ? 1u : 0u;
     {

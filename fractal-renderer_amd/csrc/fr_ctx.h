@@ -45,6 +45,12 @@ struct Opts {
     int cycle_shortcut = 0;
     int refill_minrun = -1, refill_quit16 = -1; /* -1: each kernel's own default */
     int colour_filter = 1;
+    /* the default dispatch's choice of kernel, when the caller has made it for a whole image that it renders in several
+     * launches (bands of the host path, chunks of the multi-device path): -2 = decide per launch (fr_api.hip:
+     * choose_kernel), else choose_kernel's answer (-1 none, 0 strips, 1 two passes, 2 first pass alone) and its
+     * one-strip-per-workgroup flag */
+    int kernel_hint = -2;
+    bool one_band = false;
 };
 Opts default_opts();                             /* what the fr_set_* calls have set */
 int resolve_opts(const fr_render_opts *o, Opts &out); /* NULL = defaults; validates */
@@ -134,6 +140,10 @@ int render_block_cyclic(Ctx &ctx, const fr_config *cfg, int precision, const Opt
                         void *d_out, size_t out_len, hipStream_t stream, uint64_t *rows_written);
 
 int check_precision(int precision);
+
+/* choose_kernel for rows [y0, y1) of the image as ONE launch, recorded in `o` (tile 0 only): callers that render those
+ * rows in several launches then sample the view once, not once per launch.  The calling thread must be on ctx's device. */
+void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o);
 
 /* the primary context (what fr_init selected); locks and lazily creates it.  Callers hold
  * `life_shared()` while they use it. */

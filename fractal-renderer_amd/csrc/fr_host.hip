@@ -222,15 +222,16 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     const bool trace = trace_enabled();
     const double t_start = now_ms();
 
+    const Opts *use_opts = &o;
     auto render_on = [&](hipStream_t st, uint32_t ya, uint32_t yb, uint8_t *dst) -> int {
         fr_kparams p;
-        fill_params(cfg, o, p);
+        fill_params(cfg, *use_opts, p);
         p.nrows = yb - ya;
         p.y_first = ya;
         p.block_rows = p.nrows;
         p.y_stride = 0;
         p.out_rgba = bpp == 4 ? 1u : 0u;
-        return render_device(ctx, cfg, p, precision, o, dst, st);
+        return render_device(ctx, cfg, p, precision, *use_opts, dst, st);
     };
 
     if (need < kPinThreshold) {
@@ -242,6 +243,11 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
         return FR_OK;
     }
 
+    /* 0. which kernel suits the view is decided ONCE, from a sample of all the rows (each band would otherwise take
+     *    its own sample, blocking, in front of its launch) */
+    Opts ob = o;
+    decide_kernel(ctx, cfg, precision, y0, y1, ob);
+    use_opts = &ob;
     /* 1. every band's kernel, enqueued up front: the GPU renders while the host prepares the buffer.  Bands
      *    are ~64 MiB of whole 8-row tiles (smaller over the last stretch) and alternate between two streams,
      *    so that the tail of one band's kernel — its few longest strips — overlaps the start of the next.

@@ -543,6 +543,9 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
     if (sink == Sink::Host) pins.reset(new PinProgress(dst, need));
     Job job{cfg, precision, default_opts(), block_rows, (uint32_t)(((uint64_t)cfg->height + block_rows - 1) / block_rows), n, sink,
             dst, dst_len, set->devices[0], pins.get(), set, &abort};
+    /* which kernel suits the view: decided once for the whole image (on the first device), not by every chunk launch */
+    if (hipSetDevice(set->devices[0]) == hipSuccess) decide_kernel(set->workers[0]->ctx, cfg, precision, 0, cfg->height, job.opts);
+    (void)hipGetLastError();
     fr_multi_stats stats;
     memset(&stats, 0, sizeof stats);
     stats.n_devices = n;
