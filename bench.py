@@ -391,6 +391,17 @@ def run_single(args, torch, fr, lib, native):
         return
 
     ref = img.clone()
+    # The other millisecond-scale BASELINE configs right behind the headline, while the device is in the state the
+    # headline was measured in: seconds of sustained load (the host-path legs, C3, C5 below) leave it at a lower clock for
+    # a while, and C4 read 8 % slower behind them than behind an idle period (DVFS; MI355X_MICROARCH.md).
+    if is_c2:
+        out["other_configs"] = {
+            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 2, cpu_compare=not args.no_cpu_baseline),
+            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2, cpu_compare=not args.no_cpu_baseline),
+            "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
+        }
+        img = sg.render(cfg, prec)  # the shared device buffer held the other configs meanwhile
+        torch.cuda.synchronize(device)
     # t three ways: kernel only = kernel_ms_avg above; the drop-in call as the reference's
     # caller sees it, into a host buffer that already exists (a GUI re-rendering), and into a FRESH one
     # (get_image returns a new Vec every call, src/lib.rs:266-267): kernel + PCIe D2H, never `value`
@@ -438,14 +449,7 @@ def run_single(args, torch, fr, lib, native):
     # the other single-GPU BASELINE configs, driver-timed in the same run (C3 is ~1.2 s a step: 2 steps)
     if is_c2:
         out["gui_latency"] = gui_latency(fr)
-        # (the millisecond-scale configs first: C3's four seconds of full-power compute leave the device at a lower clock
-        # for a while — C4 measured right behind it read 8 % slower than on a device that had idled)
-        out["other_configs"] = {
-            "C4": other_config_line(sg, fr, "C4", "julia", 4096, "f32", 10, 2, cpu_compare=not args.no_cpu_baseline),
-            "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2, cpu_compare=not args.no_cpu_baseline),
-            "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
-            "C3": other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1),
-        }
+        out["other_configs"]["C3"] = other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1)
         # C5's image (65536^2, 12.9 GB) on ONE device: what each of 8 GPUs would share out; the 8-GPU run is the driver's
         try:
             out["other_configs"]["C5_image_on_one_gpu"] = other_config_line(sg, fr, "C5's image, one GPU", "default", 1024, "f64", 2, 1,
