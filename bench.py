@@ -243,15 +243,8 @@ def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup, 
     cfg = make_config(fr, view, edge, iterations)
     m = sg.measure(cfg, prec, steps, warmup)
     pixels = cfg.width * cfg.height
-    extra = {}
-    if cpu_compare:
-        # the WHOLE image on the host (C4: 1.2e10 pixel-iterations, a second or two of CPU), byte for byte against the GPU's
-        info, colours, cpu_total = cpu_baseline(bytes(cfg), int(prec), usable_cores(), 1)
-        extra = {"cpu_bytes_identical": bool((m["image"].cpu().numpy() == colours).all()),
-                 "cpu_iteration_sum_identical": bool(cpu_total == m["total"]),
-                 "cpu_seconds": info["seconds"], "cpu_threads": info["threads"]}
     return {
-        **extra,
+        "_compare": (cfg, prec, m["total"]) if cpu_compare else None,  # resolved by whole_image_cpu_compare, after the timed legs
         "workload": "%s %dx%d max_iter=%d %s view=%s (BASELINE %s)" % (VIEWS[view][0], edge, edge, iterations, prec_name, view, name),
         "value": m["total"] * steps / m["dt"], "unit": "pixel-iterations/s", "steps": steps, "warmup": warmup,
         "ms_per_step": m["ms_per_step"], "dtype": prec_name, "pixel_iterations_per_image": m["total"],
@@ -259,6 +252,21 @@ def other_config_line(sg, fr, name, view, iterations, prec_name, steps, warmup, 
         "roofline": roofline_with_pmc(roofline_block(prec_name, m["total"], m["kernel_ms"], pixels, m["kernel"] + " (fused coordinate map + "
                                                      "orbit loop + colour map)", None), pmc_record(cfg, prec_name, view, fr.build_id())),
     }
+
+
+def whole_image_cpu_compare(sg, line):
+    """The WHOLE image of a measured config on the host (C4: 1.2e10 pixel-iterations, a second or two of CPU), byte for
+    byte against the GPU's — after the timed legs, so that the device does not idle (and drop its clock) between them."""
+    job = line.pop("_compare", None)
+    if not job:
+        return
+    cfg, prec, total = job
+    img = sg.render(cfg, prec)
+    sg.torch.cuda.synchronize(sg.device)
+    info, colours, cpu_total = cpu_baseline(bytes(cfg), int(prec), usable_cores(), 1)
+    line.update({"cpu_bytes_identical": bool((img.cpu().numpy() == colours).all()),
+                 "cpu_iteration_sum_identical": bool(cpu_total == total),
+                 "cpu_seconds": info["seconds"], "cpu_threads": info["threads"]})
 
 
 def gui_latency(fr):
@@ -400,6 +408,8 @@ def run_single(args, torch, fr, lib, native):
             "C4_f64": other_config_line(sg, fr, "C4 in f64", "julia", 4096, "f64", 10, 2, cpu_compare=not args.no_cpu_baseline),
             "C2_f32": other_config_line(sg, fr, "C2 in f32", "default", 1024, "f32", 10, 2),
         }
+        for line in out["other_configs"].values():
+            whole_image_cpu_compare(sg, line)
         img = sg.render(cfg, prec)  # the shared device buffer held the other configs meanwhile
         torch.cuda.synchronize(device)
     # t three ways: kernel only = kernel_ms_avg above; the drop-in call as the reference's
@@ -450,10 +460,12 @@ def run_single(args, torch, fr, lib, native):
     if is_c2:
         out["gui_latency"] = gui_latency(fr)
         out["other_configs"]["C3"] = other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1)
+        out["other_configs"]["C3"].pop("_compare", None)
         # C5's image (65536^2, 12.9 GB) on ONE device: what each of 8 GPUs would share out; the 8-GPU run is the driver's
         try:
             out["other_configs"]["C5_image_on_one_gpu"] = other_config_line(sg, fr, "C5's image, one GPU", "default", 1024, "f64", 2, 1,
                                                                             edge=65536)
+            out["other_configs"]["C5_image_on_one_gpu"].pop("_compare", None)
         except Exception as e:  # noqa: BLE001  (a smaller card: not an error of the headline)
             out["other_configs"]["C5_image_on_one_gpu"] = {"error": repr(e)}
         sg.image = None

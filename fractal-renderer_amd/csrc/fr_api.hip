@@ -158,7 +158,9 @@ int Ctx::create(int device) {
     }
     for (SurvSlot &ss : surv_slots) HIP_TRY(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
     hip_device = device;
-    return FR_OK;
+    /* the host-buffer entry points' device image buffer: room for a 3840 x 2160 RGBA frame from the start, so that a GUI's
+     * first frames (src/gui.rs:56-82) do not pay for its growth (a 4K first frame: 2.5-3.4 ms against 0.7-0.9 steady) */
+    return reserve(rgb, (size_t)64 << 20);
 }
 
 void Ctx::destroy() {
