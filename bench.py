@@ -291,6 +291,7 @@ def gui_latency(fr):
             for fmt, call, ch in (("rgb", lambda b: fr.get_image_rows(cfg, 0, h, fr.Precision.F64, out=b), 3),
                                   ("rgba", lambda b: fr.get_image_rgba(cfg, fr.Precision.F64, out=b), 4)):
                 buf = np.zeros((h, w, ch), dtype=np.uint8)
+                buf.fill(1)  # a buffer that EXISTS (np.zeros maps no pages: its faults were most of a 4K first call)
                 t0 = time.perf_counter()
                 call(buf)
                 first = (time.perf_counter() - t0) * 1e3
@@ -307,8 +308,8 @@ def gui_latency(fr):
         small.width, small.height = 750, 500
         big = make_config(fr, view, 16, 50)
         big.width, big.height = 1500, 1000
-        sbuf = np.zeros((500, 750, 3), dtype=np.uint8)
-        bbuf = np.zeros((1000, 1500, 3), dtype=np.uint8)
+        sbuf = np.ones((500, 750, 3), dtype=np.uint8)
+        bbuf = np.ones((1000, 1500, 3), dtype=np.uint8)
         redraw, shots = [], []
 
         def render_thread():
