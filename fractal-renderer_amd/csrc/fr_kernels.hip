@@ -21,11 +21,13 @@
  *   image assembly   [src/lib.rs:253-270]  bytes r,g,b at 3*(row*ncols + col); a wave writes 8-pixel
  *                    (24-byte) runs of 8 rows per tile, 192-byte runs per strip row.
  *
- * Kernels: escape_strip_kernel (default); escape_first_kernel + escape_queue_kernel<.., 1> (two passes: the
- * default for Julia images from 2048^2 up — strips to the end of their first episodes, then persistent waves
- * over the survivor lists); escape_queue_kernel<.., 0> (the work queue over the image, tile = 10);
- * escape_refill_kernel (tile = 9, the opt-in periodicity shortcut, COUNT / ESCAPE outputs of large Julia
- * images); escape_kernel (the first, 4-wave design; kept for the tile-shape study); palette_kernel,
+ * Kernels: escape_strip_kernel (small launches; large interior-heavy views); escape_first_kernel (round 3: 7-tile strips
+ * in episodes, lanes past T frozen and finished once per tile, the common tile in one asm block) — alone (tile = 13) or
+ * followed by escape_queue_kernel<.., 1> over the survivor lists (two passes, tile = 11), which of the three a large
+ * launch gets being decided from view_sample_kernel's sample of the image (fr_api.hip: choose_kernel);
+ * escape_first_v1_kernel (round 2's first pass, tile = 12, kept for A/B); escape_queue_kernel<.., 0> (the work queue
+ * over the image, tile = 10); escape_refill_kernel (tile = 9, the opt-in periodicity shortcut, COUNT / ESCAPE outputs of
+ * large Julia images); escape_kernel (the first, 4-wave design; kept for the tile-shape study); palette_kernel,
  * colour_kernel, recursive_batch_kernel; math_probe_kernel, nu_scan_kernel, cast_scan_kernel (test hooks).
  */
 #include "fr_kernels.h"

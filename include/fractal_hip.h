@@ -313,13 +313,15 @@ int fr_last_kernel_ms(float *ms);
 int fr_last_kernel_name(char *buf, size_t buf_len);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
- * 0 = default (one-wave workgroups rendering strips of 8x8 tiles, strip length by image size);
+ * 0 = default: strips of 8x8 tiles (strip length by image size) for launches under 65 536 tiles; from there up two passes
+ *     (11) for Julia images and strips otherwise; from 131 072 tiles up whichever of strips / 13 / 11 a sample of the
+ *     image calls for (fr_set_dispatch_sampling);
  * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
  * 9 = 7-tile strips with lane refill;
  * 10 = the work-queue kernel (persistent waves drawing 64x32-pixel patches from a device-wide counter, unchecked
  *      blocks of iterations, results finished and coloured 64 at a time; RGB renders of an escape-time algorithm
  *      whose loop plan allows the scaled form — otherwise it acts as 9);
- * 11 = two passes (the default for Julia images of 2048^2 pixels and more): 7-tile strips run every pixel through episodes of a few
+ * 11 = two passes: 7-tile strips run every pixel through episodes of a few
  *      dozen iterations and colour what has escaped, tile by tile; a tile whose running lanes fall under a
  *      threshold hands them — position, iterations done, output position — to lists in device memory, which the
  *      work-queue kernel's persistent waves then finish.  Same conditions as 10 (otherwise it acts as 9).  The
@@ -328,7 +330,8 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
  *      entries) — C4 in f32: 671 MB per buffer, 2 GB for the ring.  The ring is allocated when the first launch that
  *      needs lists arrives and re-allocated only for a launch that needs more: the one allocation a device-pointer
  *      render can block on (~15 ms, once).  A list that is full costs speed only;
- * 13 = that first pass alone: no tile is handed over (every lane finishes in place), no lists, no second kernel;
+ * 12 = two passes with round 2's first-pass kernel (kept for comparisons: tools/c4_ab.py);
+ * 13 = the first pass of 11 alone: no tile is handed over (every lane finishes in place), no lists, no second kernel;
  * 6401, 3202, 1604, 808 = the 4-wave-workgroup kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave
  * pixel footprint. */
 int fr_set_tile(int tile);

@@ -67,6 +67,11 @@ extern "C" {
     // one process, several GPUs (include/fractal_hip.h, "get_image across several GPUs from ONE process")
     pub fn fr_init_devices(devices: *const c_int, n: c_int) -> c_int;
     pub fn fr_render_rgb8_multi(cfg: *const fr_config, precision: c_int, block_rows: u32, out: *mut u8, out_len: usize) -> c_int;
+    // a frame buffer that is rendered into again and again: pin it once; unpin before freeing it
+    pub fn fr_pin_host_buffer(ptr: *mut c_void, len: usize) -> c_int;
+    pub fn fr_unpin_host_buffer(ptr: *mut c_void) -> c_int;
+    // the default dispatch's one blocking step (a 256-tile sample of images of 4096 x 2048 pixels and more): 0 = off
+    pub fn fr_set_dispatch_sampling(enabled: c_int) -> c_int;
     // Algo::BarnsleyFern (src/lib.rs:271-319, 417-463) on the GPU
     pub fn fr_render_fern_rgb8(cfg: *const fr_config, threads: u32, seed: u64, walkers: u32, out: *mut u8, out_len: usize) -> c_int;
 }
