@@ -108,7 +108,7 @@ struct Ctx {
         bool one_band = false;
         double lane_fraction = 0.0;
     };
-    static constexpr int kViewChoices = 8;
+    static constexpr int kViewChoices = 32; /* (a rank of a multi-GPU run renders its share in up to a dozen chunk launches per image, each its own view) */
     ViewChoice view_choices[kViewChoices];
     unsigned view_next = 0;
     std::mutex palette_mu; /* guards both rings */

@@ -339,7 +339,7 @@ int fr_set_tile(int tile);
 /* The default dispatch (tile 0) chooses between strips and two passes from the IMAGE: for launches of 131 072
  * tiles (4096 x 2048 pixels) and more it renders a sample of 256 tiles through the plain loop (~20 us of device time
  * on a stream of the library's own, ~40 us of the caller's) and takes two passes when one-tile-per-wave rendering would
- * keep less than 0.8 of its lanes busy.  The last eight (view, launch) pairs are remembered.  This is the ONE step of
+ * keep less than 0.8 of its lanes busy.  The last 32 (view, launch) pairs are remembered.  This is the ONE step of
  * the device-pointer entry points that blocks the calling thread; 0 switches it off (then: two passes for Julia
  * images from 2048^2 up, strips otherwise, as for smaller launches).  Same bytes either way. */
 int fr_set_dispatch_sampling(int enabled);
