@@ -519,3 +519,55 @@ def test_default_dispatch_chooses_the_kernel_from_a_sample_of_the_image(fr, lib)
     finally:
         _native.check(lib.fr_set_dispatch_sampling(1))
         _native.check(lib.fr_set_profiling(0))
+
+
+@pytest.mark.parametrize("prec_name", ["f64", "f32"])
+def test_view_sample_statistics_match_the_oracles_escape_counts(fr, lib, prec_name):
+    """The sample the default dispatch decides on (view_sample_kernel) against the same statistics
+    computed from the ORACLE's escape counts, exactly (they are integers): executed iterations, 64 x the tiles' longest
+    orbits, tiles, lanes at the cap, and — replaying the first pass's episode schedule per tile — lanes handed over,
+    lane-iterations idled by finishing them in place, iterations they still have to run."""
+    from fractal_renderer_amd import _native
+
+    oprec, prec = (O.F32, 1) if prec_name == "f32" else (O.F64, 0)
+    for algo, kw in ((O.JULIA, dict(julia_set=(-0.8, 0.156), iterations=700)), (O.MANDELBROT, dict(iterations=300)),
+                     (O.MANDELBROT, dict(iterations=5000, pos=(-0.7436, 0.1402), scale=(200.0, 200.0)))):
+        w, h = 1031, 777  # ragged: tile origins are cell centres aligned down to 8
+        ocfg = O.cli_config(w, h, algo, **kw)
+        cfg = to_fr(fr, ocfg)
+        st = (C.c_double * 8)()
+        _native.check(lib.fr_debug_sample_view(C.byref(cfg), prec, st))
+        _, iters = O.escape_rows(ocfg, oprec)
+        iters = iters.reshape(h, w).astype(np.int64)
+        cap = ocfg.iterations
+        cap_s = min(cap, 4096)
+        executed_all = np.minimum(np.where(iters < cap, iters + 1, cap), cap_s)  # the sample's loop stops at cap_s
+        tot = dict(sum=0, mx=0, tiles=0, capped=0, handed=0, waste=0, rest=0)
+        for tj in range(16):
+            for ti in range(16):
+                col0 = ((2 * ti + 1) * w // 32) & ~7
+                row0 = ((2 * tj + 1) * h // 32) & ~7
+                ex = np.zeros((8, 8), np.int64)
+                blk = executed_all[row0:row0 + 8, col0:col0 + 8]
+                ex[:blk.shape[0], :blk.shape[1]] = blk  # lanes past the image edge count 0
+                valid = np.zeros((8, 8), bool)
+                valid[:blk.shape[0], :blk.shape[1]] = True
+                mx = int(ex.max())
+                tot["sum"] += int(ex.sum()); tot["mx"] += 64 * mx; tot["tiles"] += 1
+                tot["capped"] += int((valid & (ex == cap_s)).sum())
+                e, ln, hands = 64, 64, False
+                nrun = 0
+                while e < mx:
+                    nrun = int((ex > e).sum())
+                    if nrun < 48:
+                        hands = nrun > 0
+                        break
+                    if e >= 8 * 64 and ln < 16 * 64:
+                        ln += ln
+                    e += ln
+                rest = int(np.maximum(ex - e, 0).sum())
+                if hands:
+                    tot["handed"] += nrun; tot["waste"] += 64 * (mx - e) - rest; tot["rest"] += rest
+        got = dict(sum=st[0], mx=st[1], tiles=st[2], capped=st[3], handed=st[4], waste=st[5], rest=st[7])
+        assert {k: int(v) for k, v in got.items()} == tot, (prec_name, algo, kw)
+        assert st[6] == pytest.approx(tot["sum"] / tot["mx"])
