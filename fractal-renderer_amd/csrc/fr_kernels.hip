@@ -2981,6 +2981,9 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint) {
         /* which of the two suits the IMAGE is measured where that pays (hint: 1 two passes, 0 strips — fr_api.hip:
          * choose_kernel); without a measurement, by the algorithm: Julia views are mostly short orbits with a heavy tail */
         if (hint == 0 || (hint < 0 && p.algo != 2)) return false;
+        /* ... and only where a tail can be long: under a cap of 512 the lists have nothing to save (a 256-iteration dust at
+         * 2048^2: 0.055 ms in two passes, 0.039 in strips; profiles/r03_kernel_choice_views.txt, mid-size section) */
+        if (hint < 0 && p.iterations < 512u) return false;
         p.first_only = hint == 2 ? 1u : 0u;
     } else if (tile == 13) {
         p.first_only = 1u;

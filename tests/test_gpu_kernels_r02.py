@@ -229,7 +229,7 @@ def test_two_pass_render_matches_the_oracle(fr, lib, case):
 
 def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, lib):
     """Five host threads, each on its own stream, render Julia images large enough for the default dispatch to
-    take two passes (>= 65 536 tiles): they contend for the context's three survivor-list buffers and sixteen
+    take two passes (>= 65 536 tiles, caps of 512 and more): they contend for the context's three survivor-list buffers and sixteen
     counter slots.  Then the host-buffer entry point, which renders the image in bands on two streams."""
     import threading
 
@@ -237,7 +237,7 @@ def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, l
     from fractal_renderer_amd import _native
 
     ocfgs = [O.cli_config(2048, 2048, O.JULIA, julia_set=js, iterations=it)
-             for js, it in (((-0.8, 0.156), 600), ((0.285, 0.01), 300), ((-0.4, 0.6), 900), ((-0.8, 0.156), 150), ((0.001, 0.8), 500))]
+             for js, it in (((-0.8, 0.156), 600), ((0.285, 0.01), 512), ((-0.4, 0.6), 900), ((-0.8, 0.156), 700), ((0.001, 0.8), 520))]
     cfgs = [to_fr(fr, c) for c in ocfgs]
     precs = [0, 1, 0, 1, 0]
     want = []
