@@ -4,8 +4,9 @@
 Static side: the gfx950 ISA of escape_first_kernel<T, 4, 7, 4> (hipcc --cuda-device-only -S, the build's flags); its
 all-asm tile path is split at its labels (prologue / first block / block loop / finish entry / finishing loop) and the
 compiler's colour block behind it is taken from the listing; every instruction is classed by issue cost:
-    f32-rate   v_{add,sub,mul,fma,mov,cndmask,cmp,cmpx,cvt_pk_u8,floor,max,min}_f32/b32   (2 cycles nominal, 2.4 measured)
-    f64/int    v_*_f64, v_mov_b64, 32-bit integer and logic, 64-bit address arithmetic   (4 nominal, 4.4 measured)
+    f32-rate   v_{add,sub,mul,fma,mov,cndmask,cvt_pk_u8,floor,max,min}_f32/b32             (2 cycles nominal, 2.4 measured)
+    f64/int    v_*_f64, v_mov_b64, 32-bit integer and logic, 64-bit address arithmetic, and EVERY compare — v_cmp / v_cmpx
+               _f32 issue at the f64 rate too (profiles/r03_valu_rates.txt: 4.4 cycles)    (4 nominal, 4.4 measured)
     quarter    v_log_f32, v_rcp_*, v_cvt_f32_f64 / f64 conversions                        (8)
     lane       v_readlane / v_writelane / v_readfirstlane (a vector-issue slot each)
     salu       s_* except waits and nops (one per ~4 cycles per SIMD, shared by its waves)
@@ -42,6 +43,8 @@ def classify(ins):
         return "lane"
     if m.startswith(("v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_")) or "cvt_f32_f64" in m or "cvt_f64_f32" in m:
         return "quarter"
+    if m.startswith("v_cmp"):
+        return "f64/int"
     if "_f64" in m or m.startswith(("v_mov_b64", "v_lshl_add_u64", "v_mad_u64", "v_lshlrev_b64", "v_pk_")):
         return "f64/int"
     if re.search(r"_(u32|i32|u16|i16|b16)(_|$)", m) and not m.startswith(("v_mov_b32", "v_cndmask", "v_cvt_f32_u32", "v_cvt_pk_u8")):

@@ -67,6 +67,19 @@ DEF_KERNEL(k_pk_mul_f32, PKMULF(0), PKMULF(1), PKMULF(2), PKMULF(3), PKMULF(4), 
 DEF_KERNEL(k_pk_add_f32, PKADDF(0), PKADDF(1), PKADDF(2), PKADDF(3), PKADDF(4), PKADDF(5), PKADDF(6), PKADDF(7))
 #define MAX64(n) "v_max_f64 %" #n ", %" #n ", %16"
 DEF_KERNEL(k_max_f64, MAX64(0), MAX64(1), MAX64(2), MAX64(3), MAX64(4), MAX64(5), MAX64(6), MAX64(7))
+// f32 compares (VOPC writing vcc / exec): f32 rate or the 32-bit integer rate?  (round 3: can the block test of an
+// f64 orbit loop compare the HIGH dword of |z|^2 at the f32 rate?)
+#define CMPF(n) "v_cmp_gt_f32 vcc, " U##n ", %17"
+DEF_KERNEL(k_cmp_f32, CMPF(0), CMPF(1), CMPF(2), CMPF(3), CMPF(4), CMPF(5), CMPF(6), CMPF(7))
+#define CMPXF(n) "v_cmpx_le_f32 " U##n ", " U##n
+DEF_KERNEL(k_cmpx_f32, CMPXF(0), CMPXF(1), CMPXF(2), CMPXF(3), CMPXF(4), CMPXF(5), CMPXF(6), CMPXF(7))
+#define CMPXD(n) "v_cmpx_le_f64 %" #n ", %" #n
+DEF_KERNEL(k_cmpx_f64, CMPXD(0), CMPXD(1), CMPXD(2), CMPXD(3), CMPXD(4), CMPXD(5), CMPXD(6), CMPXD(7))
+// seven f64 ops + one compare: f64 compare against f32 compare
+DEF_KERNEL(k_mix_7d_cmpd, OP3("v_mul_f64", 0), OP3("v_add_f64", 1), OP3("v_add_f64", 2), OP3("v_mul_f64", 3),
+           OP3("v_add_f64", 4), OP3("v_add_f64", 5), OP3("v_mul_f64", 6), CMPXD(7))
+DEF_KERNEL(k_mix_7d_cmpf, OP3("v_mul_f64", 0), OP3("v_add_f64", 1), OP3("v_add_f64", 2), OP3("v_mul_f64", 3),
+           OP3("v_add_f64", 4), OP3("v_add_f64", 5), OP3("v_mul_f64", 6), CMPXF(7))
 // mixed: 3 mul + 4 add + 1 cmp (the minimal orbit iteration)
 DEF_KERNEL(k_mix_orbit, OP3("v_mul_f64", 0), OP3("v_add_f64", 1), OP3("v_add_f64", 2), OP3("v_mul_f64", 3),
            OP3("v_add_f64", 4), OP3("v_add_f64", 5), OP3("v_mul_f64", 6), CMP(7))
@@ -105,6 +118,8 @@ int main() {
     struct K { const char *name; kern_t fn; } ks[] = {
         {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_fma_f64", k_fma_f64}, {"v_max_f64", k_max_f64},
         {"v_cmp_gt_f64", k_cmp_f64}, {"v_cmp_gt_u32", k_cmp_u32}, {"v_max_u32", k_max_u32},
+        {"v_cmp_gt_f32", k_cmp_f32}, {"v_cmpx_le_f32", k_cmpx_f32}, {"v_cmpx_le_f64", k_cmpx_f64},
+        {"7 f64 + v_cmpx_le_f64", k_mix_7d_cmpd}, {"7 f64 + v_cmpx_le_f32", k_mix_7d_cmpf},
         {"v_mov_b32", k_mov_b32}, {"v_mov_b64", k_mov_b64}, {"v_mul_f32", k_mul_f32},
         {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32},
         {"mix 3mul+4add+cmp f64", k_mix_orbit}, {"mix f64/u32 alternating", k_mix_f64_u32},
