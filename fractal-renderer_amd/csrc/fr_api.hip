@@ -55,7 +55,7 @@ std::atomic<uint32_t> g_two_pass_list_entries{0};          /* test aid, see fr_d
 
 bool valid_tile(int tile) {
     switch (tile) {
-    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 12: case 13: case 6401: case 3202: case 1604: case 808:
+    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 6401: case 3202: case 1604: case 808:
         return true;
     default:
         return false;
@@ -115,7 +115,7 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     o = default_opts();
     if (!in) return FR_OK;
     if (in->size < sizeof(fr_render_opts)) return fail(FR_ERR_INVALID_ARGUMENT, "fr_render_opts.size is too small (use fr_render_opts_init)");
-    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 6401, 3202, 1604 or 808");
+    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 6401, 3202, 1604 or 808");
     if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
     if (in->refill_minrun < -1 || in->refill_quit16 < -1 || in->refill_quit16 == 0 || in->refill_quit16 > 16)
@@ -425,12 +425,12 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
      * once 24 lanes are free and 8 iterations were done */
     p.refill_minrun = o.refill_minrun < 0 ? 32u : (uint32_t)o.refill_minrun;
     p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
-    p.queue_minrun = (o.refill_minrun < 0 || o.tile == 11 || o.tile == 12 || o.tile == 13) ? 8u : (uint32_t)o.refill_minrun;
+    p.queue_minrun = (o.refill_minrun < 0 || (o.tile >= 11 && o.tile <= 14)) ? 8u : (uint32_t)o.refill_minrun;
     /* tile 11: minrun = the first pass's episode length, quit16 = the lanes (in 16ths of a wave) a tile must
      * keep running to stay in the first pass; the second pass keeps its own defaults */
-    p.first_keep = ((o.tile == 11 || o.tile == 12 || o.tile == 13) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
-    p.two_pass_cap = ((o.tile == 11 || o.tile == 12 || o.tile == 13) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
-    p.queue_want = (o.refill_quit16 < 0 || o.tile == 11 || o.tile == 12 || o.tile == 13) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
+    p.first_keep = ((o.tile >= 11 && o.tile <= 14) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
+    p.two_pass_cap = ((o.tile >= 11 && o.tile <= 14) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
+    p.queue_want = (o.refill_quit16 < 0 || (o.tile >= 11 && o.tile <= 14)) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
     {
         /* tuning aid: the second pass's own policy under the two-pass render (whose fr_set_refill_policy numbers
          * steer the first pass): FR_DEBUG_QUEUE_WANT / FR_DEBUG_QUEUE_MINRUN */
@@ -651,11 +651,12 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
-    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 13;
+    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 14;
     bool one_band = o.one_band;
     const int hint = o.kernel_hint != -2 ? o.kernel_hint : choose_kernel(ctx, cfg, p, precision, o, &one_band);
     const bool want_two_pass = fr_wants_two_pass(p, precision, o.tile, hint);
     p.first_one_band = one_band ? 1u : 0u;
+    p.second_v1 = (o.tile == 12 || o.tile == 14) ? 1u : 0u; /* 12 = round 2's two kernels, 14 = its second pass behind this round's first */
     {
         static const int dbg = getenv("FR_DEBUG_FIRST_ONE_BAND") ? atoi(getenv("FR_DEBUG_FIRST_ONE_BAND")) : -1; /* tuning aid */
         if (dbg >= 0) p.first_one_band = dbg ? 1u : 0u;

@@ -85,6 +85,7 @@ struct fr_kparams {
     uint32_t first_keep;   /* a tile stays in the first pass while at least this many of its lanes are running */
     uint32_t two_pass_cap; /* the caller's wish for first_cap (0 = the default) */
     uint32_t first_only;   /* 1: the first pass keeps every tile to its end (no lists, no second pass) */
+    uint32_t second_v1;    /* 1: the survivor lists are drained by round 2's kernel, escape_queue_kernel<.., 1> (comparison only) */
     uint32_t first_one_band; /* 1: one 7-tile strip per workgroup whatever the launch size (views of long orbits: workgroups of
                               * 28 tiles differ too much in cost to balance) */
     uint32_t surv_sub_capacity;

@@ -1191,6 +1191,10 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
     }
 }
 
+/* the lanes (of EXEC) with `b` set: the builtin on the i1 itself — s_and_b64 with EXEC; HIP's __ballot() converts the
+ * boolean to an integer and compares it again, two vector instructions */
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 /* bit `lane` of a wave-uniform mask, as a per-lane boolean */
 __device__ __forceinline__ bool lane_in(unsigned long long m) {
     uint32_t b;
@@ -1465,13 +1469,17 @@ __device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, floa
 
 /* one pixel per lane to `base + off` (a wave-uniform base in scalar registers, a 32-bit byte offset per lane: no
  * vector address arithmetic): r,g,b as one 16-bit store — unaligned, as the compiler itself emits them on this
- * target — plus the high byte of the same register, or r,g,b,255 as one dword */
+ * target — plus the high byte of the same register, or r,g,b,255 as one dword.
+ * The s_nop: a memory instruction that reads a scalar register written by a VECTOR instruction needs five wait states
+ * on this target, and the compiler, which inserts them in its own code, does not look inside an asm statement: when
+ * it restores a spilled `base` with v_readlane right in front of this one, the store went out with the register's OLD
+ * upper half (escape_second_kernel<double>, round 3: "memory access fault", "beyond the largest legal address"). */
 __device__ __forceinline__ void store_packed(uint8_t *base, uint32_t off, uint32_t packed, uint32_t bpp) {
     if (bpp == 4u) {
         const uint32_t v = packed | 0xFF000000u;
-        asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
     } else {
-        asm volatile("global_store_short %0, %1, %2\n\tglobal_store_byte_d16_hi %0, %1, %2 offset:2" : : "v"(off), "v"(packed), "s"(base) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_short %0, %1, %2\n\tglobal_store_byte_d16_hi %0, %1, %2 offset:2" : : "v"(off), "v"(packed), "s"(base) : "memory");
     }
 }
 
@@ -2541,6 +2549,415 @@ __global__ __launch_bounds__(64) void escape_queue_kernel(const fr_kparams p, co
 #undef FR_PHASE_END
 }
 
+/* ---- second pass, second form (round 3) --------------------------------------------------------------
+ *
+ * escape_queue_kernel<.., 1> above spends, on C4, four vector instructions in ten OUTSIDE its main loop
+ * (profiles/r03_c4_f64_rocprofv3.txt: 5.0e8 of them for 5.35e7 wave-iterations at 6.75): per 64-entry chunk 2.5 refills,
+ * 2.5 retirements and one finishing pass, each written for the general case — results leave the loop converted back to
+ * re / im (four multiplies and seven LDS words per lane), the finishing pass runs the unscaled 8-instruction iteration,
+ * colours every lane through the general colour path (both stages of the filter as soon as one lane of 64 is at the cap,
+ * which is six batches in seven) and stores three bytes per pixel through 64-bit addresses.  This kernel is the same
+ * schedule — persistent one-wave workgroups, 64-entry chunks claimed in batches from the 64 lists, unchecked blocks with
+ * freezing lanes, an LDS stack of results finished 64 at a time — with the first pass's (escape_first_kernel) means:
+ *   - the state stays in the scaled form from the list to the colour: a chunk is converted ONCE, by 64 lanes, when it is
+ *     opened (X = 2re, Y = 2im, 2c, the count as f32) and a refill is two or three LDS reads and two squares; a result is
+ *     pushed as it stands (X, Y | count, column, row | 2c for Mandelbrot: two or three wide LDS writes, one address);
+ *   - the finishing pass is finish_scaled (9 instructions per exact iteration, no conversion), then the filter's f32 stage
+ *     in the first pass's form (colour_fast32) for the lanes that ESCAPED — per lane, not per wave: the lanes at the cap and
+ *     the rare undecided ones alone take the general path — and one 16-bit + one 8-bit store at a 32-bit offset;
+ *   - which lanes are busy, still running, or leaving are 64-bit masks; the main loop sets its own EXEC from the mask
+ *     and returns scalars; the per-lane test against the cap runs only when the wave's largest count is within M of it.
+ * Same bytes: a pixel's orbit is recursive()'s arithmetic whichever loop runs it (see "orbit loop, scaled form"). */
+#define FR_SB_ASM(SFX, BLOCK_ITS, STEP)                                            \
+    "s_mov_b64 %[sorig], exec\n"                                                   \
+    "s_mov_b64 exec, %[mask]\n"                                                    \
+    "s_mov_b32 %[si], 0\n"                                                         \
+    ".Lsloop_%=:\n" BLOCK_ITS                                                      \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                                             \
+    "v_add_f32 %[cnt], %[cnt], " STEP "\n"                                         \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"                                          \
+    "s_add_u32 %[si], %[si], 1\n"                                                  \
+    "s_cbranch_execz .Lsdone_%=\n"                                                 \
+    "s_bcnt1_i32_b64 %[scnt], exec\n"                                              \
+    "s_cmp_gt_u32 %[scnt], %[thr]\n"                                               \
+    "s_cbranch_scc0 .Lsmaybe_%=\n"                                                 \
+    ".Lscont_%=:\n"                                                                \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc1 .Lsloop_%=\n"                                                  \
+    "s_branch .Lsdone_%=\n"                                                        \
+    ".Lsmaybe_%=:\n"                                                               \
+    "s_cmp_lt_u32 %[si], %[minrun]\n"                                              \
+    "s_cbranch_scc1 .Lscont_%=\n"                                                  \
+    ".Lsdone_%=:\n"                                                                \
+    "s_mov_b64 %[srun], exec\n"                                                    \
+    "s_mov_b64 exec, %[sorig]\n"
+
+/* One run of the main loop for the lanes of `mask` (not empty; each with A + B <= 4T and count + M * nblocks <= cap,
+ * nblocks >= 1): as queue_block_run, but the mask is an argument and everything that comes back is a scalar. */
+template <typename T, int M>
+__device__ __forceinline__ uint32_t second_block_run(unsigned long long mask, uint32_t nblocks, T &X, T &Y, T &A, T &B, T c2re,
+                                                     T c2im, typename UBits<T>::type t4lim, float &cnt, uint32_t thr,
+                                                     uint32_t minrun, unsigned long long &running) {
+    T t, q;
+    unsigned long long sorig, srun;
+    uint32_t si, scnt;
+#define FR_SB_OPERANDS                                                                                          \
+    : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [cnt] "+v"(cnt), [t] "=&v"(t), [q] "=&v"(q),          \
+      [sorig] "=&s"(sorig), [srun] "=&s"(srun), [si] "=&s"(si), [scnt] "=&s"(scnt)                              \
+    : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n] "s"(nblocks), [thr] "s"(thr), \
+      [minrun] "s"(minrun)                                                                                      \
+    : "vcc", "scc"
+    if constexpr (sizeof(T) == 8) {
+        if constexpr (M == 4)
+            asm volatile(FR_SB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "4.0") FR_SB_OPERANDS);
+        else
+            asm volatile(FR_SB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "2.0") FR_SB_OPERANDS);
+    } else {
+        if constexpr (M == 4)
+            asm volatile(FR_SB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0") FR_SB_OPERANDS);
+        else
+            asm volatile(FR_SB_ASM("f32", FR_SC_IT("f32") FR_SC_IT("f32"), "2.0") FR_SB_OPERANDS);
+    }
+    running = srun;
+    return si;
+}
+
+template <typename T, int M>
+__global__ __launch_bounds__(64) void escape_second_kernel(const fr_kparams p, const fr_kout out) {
+    static_assert(M == 4 || M == 2, "the main loop is the scaled form in blocks of M");
+    static_assert(FR_SURV_QUEUES == 64 && FR_SURV_CHUNK == 64, "one list counter per lane; a chunk is loaded one entry per lane");
+    typedef typename Pair<T>::type T2;
+    typedef typename UBits<T>::type UB;
+    /* the open chunk, converted: (X, Y), 2c (Mandelbrot), {count as f32 bits, output column, output row, count} */
+    __shared__ T2 s_cxy[FR_SURV_CHUNK], s_cc2[FR_SURV_CHUNK];
+    __shared__ uint4 s_cmeta[FR_SURV_CHUNK];
+    /* the stack of unfinished results, in the same form */
+    __shared__ T2 q_xy[kQStack], q_c2[kQStack];
+    __shared__ uint4 q_meta[kQStack];
+    extern __shared__ uint32_t s_dyn_palette[]; /* smooth == false: the palette, staged once */
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *s_pal = nullptr;
+    if (p.palette != nullptr) {
+        for (uint32_t k = lane; k < p.palette_entries; k += 64) s_dyn_palette[k] = p.palette[k];
+        s_pal = s_dyn_palette;
+        __syncthreads();
+    }
+    const double *tab = &g_log2_tab[0][0]; /* the exact colour path is rare here: the table stays in L2 */
+    const bool julia = p.algo == 2;
+    const T squared = sizeof(T) == 8 ? (T)(p.limit * p.limit) : (T)((float)p.limit * (float)p.limit);
+    const T t4v = (T)4 * (T)p.skip_t, lim4v = (T)4 * squared;
+    const UB t4lim = uniform_bits<T>(t4v), lim4 = uniform_bits<T>(lim4v);
+    const uint32_t cap = p.iterations; /* < 2^24 (the host sends larger caps elsewhere): counts are exact in f32 */
+    const float capf = (float)cap;
+    const uint32_t queue_want = p.queue_want, queue_minblocks = (p.queue_minrun + M - 1) / M;
+    const T j2re = (T)p.julia_re + (T)p.julia_re, j2im = (T)p.julia_im + (T)p.julia_im;
+    uint32_t *const counter = p.work_counter;
+    const uint32_t first_cap = p.first_cap;
+    bool fast_colour, narrow;
+    uint32_t bpp, ncols;
+    {
+        FR_COLD_PARAMS(kp);
+        fast_colour = kp->colour_filter32 && kp->smooth && kp->palette == nullptr;
+        bpp = kp->out_rgba ? 4u : 3u;
+        ncols = kp->ncols;
+        const uint64_t rows = kp->out_in_place ? kp->height : kp->nrows; /* no output row lies beyond it */
+        narrow = rows * (uint64_t)ncols <= 0xFFFFFFFFull / bpp;
+    }
+    const unsigned long long t_start = out.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t tr_chunks = 0, tr_episodes = 0, tr_colour = 0, tr_iters = 0;
+
+    /* work claiming: as escape_queue_kernel<.., 1> (batches of chunks from 64 counters, guided self-scheduling) */
+    uint32_t list_len;
+    {
+        const uint32_t raw = p.surv_counts[lane * FR_SURV_COUNT_STRIDE];
+        list_len = raw < p.surv_sub_capacity ? raw : p.surv_sub_capacity;
+    }
+    const uint32_t units_lane = (list_len + FR_SURV_CHUNK - 1u) / FR_SURV_CHUNK;
+    uint32_t cur_q = blockIdx.x & (FR_SURV_QUEUES - 1u);
+    uint32_t batch_next = 0, batch_end = 0;
+    const uint32_t claim_div = 2u * (gridDim.x / FR_SURV_QUEUES + 1u);
+    auto take_unit = [&](uint32_t &j) __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (batch_next < batch_end) {
+                j = batch_next++;
+                return true;
+            }
+            const uint32_t units_q = __builtin_amdgcn_readlane(units_lane, cur_q);
+            const uint32_t left = units_q > batch_end ? units_q - batch_end : 0u;
+            uint32_t size = left / claim_div;
+            size = size < 1u ? 1u : (size > 4u ? 4u : size);
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(counter + cur_q * FR_SURV_COUNT_STRIDE, size);
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < units_q) {
+                batch_next = got;
+                batch_end = got + size < units_q ? got + size : units_q;
+                continue;
+            }
+            const uint32_t claimed = __hip_atomic_load(counter + lane * FR_SURV_COUNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long m = ballot64(claimed < units_lane);
+            if (m == 0ull) return false;
+            const uint32_t r = (cur_q + 1u) & 63u;
+            const unsigned long long m2 = r ? (m >> r) | (m << (64u - r)) : m;
+            cur_q = (cur_q + 1u + (uint32_t)__builtin_ctzll(m2)) & 63u;
+            batch_next = batch_end = __builtin_amdgcn_readlane(claimed, cur_q);
+        }
+    };
+    /* the NEXT chunk, on its way into registers (one entry per lane) while the open one is worked on */
+    uint32_t nx_n = 0;
+    T2 pf_z, pf_c;
+    uint2 pf_pos = make_uint2(0u, 0u);
+    uint32_t pf_cnt = 0;
+    pf_z.x = pf_z.y = pf_c.x = pf_c.y = (T)0;
+    auto prefetch_chunk = [&]() __attribute__((always_inline)) {
+        uint32_t j;
+        nx_n = 0;
+        if (take_unit(j)) {
+            FR_COLD_PARAMS(kp);
+            const uint32_t len = __builtin_amdgcn_readlane(list_len, cur_q);
+            const size_t base = (size_t)cur_q * kp->surv_sub_capacity + (size_t)j * FR_SURV_CHUNK;
+            nx_n = len - j * FR_SURV_CHUNK < FR_SURV_CHUNK ? len - j * FR_SURV_CHUNK : FR_SURV_CHUNK;
+            const size_t e = base + (lane < nx_n ? lane : 0u);
+            pf_z = static_cast<const T2 *>(kp->surv_z)[e];
+            pf_pos = reinterpret_cast<const uint2 *>(kp->surv_pos)[e];
+            pf_cnt = kp->surv_cnt[e];
+            if (!julia) pf_c = static_cast<const T2 *>(kp->surv_c)[e];
+        }
+    };
+    prefetch_chunk();
+
+    /* per-lane state of a running orbit */
+    T X = 0, Y = 0, A = 0, B = 0, c2re = j2re, c2im = j2im;
+    float cnt = 0.0f;
+    uint32_t px = 0, py = 0;
+    bool busy = false;
+    /* wave-uniform state */
+    uint32_t have_chunk = 0, exhausted = 0, next = 0, chunk_n = 0, chunk_maxcnt = 0;
+    uint32_t qcount = 0, upper = 0; /* results waiting; upper bound of the busy lanes' counts */
+
+    /* the finishing pass over `count` stack entries from `base` */
+    auto finish_and_colour = [&](uint32_t base, uint32_t count) __attribute__((always_inline)) {
+        __syncthreads();
+        const bool mine = lane < count;
+        const uint32_t e = base + (mine ? lane : 0u);
+        const T2 xy = q_xy[e];
+        const uint4 meta = q_meta[e];
+        T fX = xy.x, fY = xy.y, f2re = j2re, f2im = j2im;
+        if (!julia) {
+            const T2 c2 = q_c2[e];
+            f2re = c2.x, f2im = c2.y;
+        }
+        T fA = fX * fX, fB = fY * fY, ft = fA + fB;
+        float fc = __builtin_bit_cast(float, meta.x);
+        /* did the last iteration it ran escape?  (the earlier ones of its block cannot have: plan_loop; an entry that
+         * has run none has not been tested yet: recursive() tests AFTER an iteration; NaN: no, as in the reference) */
+        const bool escaped0 = mine && fc > 0.0f && ft > lim4v;
+        bool lv = mine && !escaped0 && fc < capf;
+        unsigned long long esc = ballot64(escaped0), live = ballot64(lv);
+        /* the exact loop for whoever is not done: a lane past T is 4-5 iterations from limit^2; rounds of up to 64,
+         * shorter when a lane is that close to the cap (lanes AT the cap retire: they are points of the set) */
+        while (live != 0ull) {
+            uint32_t nf = 64u;
+            if (ballot64(lv && capf - fc < 64.0f) != 0ull) {
+                live &= ~ballot64(lv && fc >= capf);
+                if (live == 0ull) break;
+                nf = cap - __builtin_amdgcn_readfirstlane(wave_max_u32(lane_in(live) ? (uint32_t)fc : 0u));
+                nf = nf > 64u ? 64u : nf;
+            }
+            const unsigned long long still = finish_scaled<T>(live, nf, fX, fY, fA, fB, ft, fc, f2re, f2im, lim4);
+            esc |= live & ~still;
+            live = still;
+            lv = lane_in(live);
+        }
+        /* ---- colour (calc/src/lib.rs:214-234): the filter's f32 stage for the lanes that escaped — (A + B) / 4 IS
+         * fl(re^2 + im^2) and the count is iters + 1, as in the first pass — the general path for the rest */
+        const unsigned long long fin = count >= 64u ? ~0ull : (1ull << count) - 1ull;
+        uint32_t packed = 0;
+        unsigned long long coloured = 0ull;
+        if (fast_colour && esc != 0ull) {
+            Filter32 f;
+            {
+                FR_COLD_PARAMS(kp);
+                f.lo = kp->filt_lo32, f.k = kp->filt_k32, f.c = kp->filt_c32;
+                f.p0 = kp->prim32[0], f.p1 = kp->prim32[2], f.p2 = kp->prim32[1]; /* colour_multiply's RGB::new(r, b, g) swap */
+            }
+            const float d32 = (float)ft * 0.25f;
+            const bool sure = d32 >= f.lo && d32 <= 0x1.ffffep119f;
+            const bool decided = colour_fast32(f, d32, fc, packed);
+            coloured = ballot64(sure && decided) & esc;
+        }
+        /* the lanes that did not escape (points of the set, at the cap) whose squared distance is within stable_limit —
+         * all of them, bar contrived limits — are `inside` pixels: colour_of's last two branches (calc/src/lib.rs:230-233) */
+        const unsigned long long stayed = fin & ~esc;
+        bool inside_done = false;
+        if (stayed != 0ull) {
+            if (lane_in(stayed)) {
+                double dist;
+                if constexpr (sizeof(T) == 8) {
+                    const T re = fX * (T)0.5, im = fY * (T)0.5;
+                    dist = (double)(re * re + im * im);
+                } else {
+                    const double zre = (double)(fX * (T)0.5), zim = (double)(fY * (T)0.5);
+                    dist = zre * zre + zim * zim;
+                }
+                FR_COLD_PARAMS(kp);
+                inside_done = !(dist > kp->stable_limit);
+                if (inside_done) {
+                    packed = 0u;
+                    if (kp->inside) /* color_multiply(secondary_color, dist), with its RGB::new(r, b, g) swap */
+                        packed = sat_u8_dev(kp->sec_f[0] * dist) | (sat_u8_dev(kp->sec_f[2] * dist) << 8) | (sat_u8_dev(kp->sec_f[1] * dist) << 16);
+                }
+            }
+        }
+        const unsigned long long rest = fin & ~coloured & ~ballot64(inside_done);
+        if (rest != 0ull) {
+            if (lane_in(rest)) {
+                const T re = fX * (T)0.5, im = fY * (T)0.5; /* exact */
+                const T r2 = re * re, i2 = im * im;         /* the reference's own re*re, im*im */
+                const uint32_t iters = lane_in(esc) ? (uint32_t)fc - 1u : cap;
+                FR_COLD_PARAMS(kp);
+                const ColourConsts cc = make_colour_consts(*kp);
+                uint8_t rgb[3];
+                colour_pixel<T>(cc, re, im, r2, i2, iters, tab, s_pal, rgb);
+                packed = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16);
+            }
+        }
+        /* ---- store (src/lib.rs:253-270) */
+        if (mine) {
+            if (narrow) {
+                store_packed(out.rgb, (meta.z * ncols + meta.y) * bpp, packed, bpp);
+            } else {
+                uint8_t *o = out.rgb + ((uint64_t)meta.z * ncols + meta.y) * bpp;
+                if (bpp == 4u) {
+                    *reinterpret_cast<uint32_t *>(o) = packed | 0xFF000000u;
+                } else {
+                    o[0] = (uint8_t)packed, o[1] = (uint8_t)(packed >> 8), o[2] = (uint8_t)(packed >> 16);
+                }
+            }
+        }
+        tr_colour++;
+        __syncthreads();
+    };
+    /* push the lanes with `who` set, as they stand */
+    auto push = [&](bool who) __attribute__((always_inline)) {
+        const unsigned long long m = ballot64(who);
+        if (m == 0ull) return;
+        if (who) {
+            const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            T2 xy;
+            xy.x = X, xy.y = Y;
+            q_xy[slot] = xy;
+            q_meta[slot] = make_uint4(__builtin_bit_cast(uint32_t, cnt), px, py, 0u);
+            if (!julia) {
+                T2 c2;
+                c2.x = c2re, c2.y = c2im;
+                q_c2[slot] = c2;
+            }
+        }
+        qcount += (uint32_t)__builtin_popcountll(m);
+        if (qcount >= 64u) {
+            finish_and_colour(qcount - 64u, 64u);
+            qcount -= 64u;
+        }
+    };
+
+    for (;;) {
+        /* ---- 1. open the next chunk when the current one is used up: convert it once, 64 entries at a time */
+        if (!have_chunk && !exhausted) {
+            if (nx_n == 0) {
+                exhausted = 1;
+            } else {
+                __syncthreads(); /* earlier reads of the chunk arrays are done */
+                T2 xy;
+                xy.x = pf_z.x + pf_z.x, xy.y = pf_z.y + pf_z.y;
+                s_cxy[lane] = xy;
+                s_cmeta[lane] = make_uint4(__builtin_bit_cast(uint32_t, (float)pf_cnt), pf_pos.x, pf_pos.y, pf_cnt);
+                if (!julia) {
+                    T2 c2;
+                    c2.x = pf_c.x + pf_c.x, c2.y = pf_c.y + pf_c.y;
+                    s_cc2[lane] = c2;
+                }
+                /* nearly every chunk's entries left the first pass after its first episode */
+                chunk_maxcnt = ballot64(lane < nx_n && pf_cnt != first_cap) == 0ull
+                                   ? first_cap
+                                   : __builtin_amdgcn_readfirstlane(wave_max_u32(lane < nx_n ? pf_cnt : 0u));
+                __syncthreads();
+                chunk_n = nx_n;
+                have_chunk = 1;
+                next = 0;
+                tr_chunks++;
+                prefetch_chunk();
+            }
+        }
+        /* ---- 2. hand unstarted entries to the free lanes */
+        unsigned long long busy_mask = ballot64(busy);
+        if (have_chunk && busy_mask != ~0ull) {
+            const unsigned long long free_mask = ~busy_mask;
+            const uint32_t pix = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
+            bool direct = false; /* this entry cannot enter the main loop: straight to the finishing pass */
+            if (!busy && pix < chunk_n) {
+                const T2 xy = s_cxy[pix];
+                const uint4 meta = s_cmeta[pix];
+                X = xy.x, Y = xy.y, A = X * X, B = Y * Y;
+                if (!julia) {
+                    const T2 c2 = s_cc2[pix];
+                    c2re = c2.x, c2im = c2.y;
+                }
+                cnt = __builtin_bit_cast(float, meta.x);
+                px = meta.y, py = meta.z;
+                /* (the scaled form is exact for this orbit: the first pass hands over only pixels of strips it ran in
+                 * the scaled form itself — admissible start and c, see strip_is_scalable) */
+                if (A + B <= t4v && meta.w + (uint32_t)M <= cap)
+                    busy = true;
+                else
+                    direct = true;
+            }
+            next += (uint32_t)__builtin_popcountll(free_mask);
+            if (next >= chunk_n) have_chunk = 0;
+            if (upper < chunk_maxcnt) upper = chunk_maxcnt;
+            push(direct);
+            busy_mask = ballot64(busy);
+        }
+        /* the chunk ran out before the free lanes did: open the next one right away */
+        if (!have_chunk && !exhausted && busy_mask != ~0ull) continue;
+        if (busy_mask == 0ull) {
+            if (!have_chunk && exhausted) break;
+            continue;
+        }
+        /* ---- 3. one run of the main loop (every busy lane: count + M <= cap) */
+        if (upper + (uint32_t)M > cap) upper = __builtin_amdgcn_readfirstlane(wave_max_u32(busy ? (uint32_t)cnt : 0u));
+        const uint32_t nblocks = (cap - upper) / (uint32_t)M;
+        const uint32_t nbusy = (uint32_t)__builtin_popcountll(busy_mask);
+        uint32_t thr = 0, minblocks = 0;
+        if (have_chunk || !exhausted) { /* more entries wait: stop once `queue_want` lanes are free */
+            /* (a saturating subtraction has no scalar form: the compiler computes it on the vector unit) */
+            thr = __builtin_amdgcn_readfirstlane(nbusy > queue_want ? nbusy - queue_want : 0u);
+            minblocks = queue_minblocks;
+        }
+        unsigned long long running;
+        const uint32_t blocks = second_block_run<T, M>(busy_mask, nblocks, X, Y, A, B, c2re, c2im, t4lim, cnt, thr, minblocks, running);
+        upper += blocks * (uint32_t)M;
+        tr_episodes++;
+        tr_iters += blocks * (uint32_t)M;
+        /* ---- 4. retire: lanes that froze past T, and — only when the largest count is that close — lanes that cannot
+         * fit another block under the cap */
+        unsigned long long leave = busy_mask & ~running;
+        if (upper + (uint32_t)M > cap) leave |= ballot64(lane_in(running) && (uint32_t)cnt + (uint32_t)M > cap);
+        if (leave != 0ull) {
+            const bool lv = lane_in(leave);
+            if (lv) busy = false;
+            push(lv);
+        }
+    }
+    /* ---- the last, partial batch */
+    if (qcount) finish_and_colour(0u, qcount);
+    if (out.trace && lane == 0) { /* fr_debug_set_queue_trace: the same record as escape_queue_kernel's, without the phase cycles */
+        unsigned long long *t = out.trace + (size_t)blockIdx.x * 16;
+        t[0] = t_start, t[1] = __builtin_amdgcn_s_memrealtime(), t[2] = tr_chunks, t[3] = tr_episodes, t[4] = tr_colour, t[5] = tr_iters;
+        t[6] = t[7] = t[8] = 0ull;
+    }
+}
+
 template <typename T, int M, int SRC>
 hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_t stream) {
     /* SRC 1: the number of chunks is known to the device only; size the persistent grid by an upper bound */
@@ -2562,14 +2979,20 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
         cached_device = dev;
     }
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, escape_queue_kernel<T, M, SRC>, 64, dyn);
+    if (SRC == 1 && !p.second_v1)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, escape_second_kernel<T, M>, 64, dyn);
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, escape_queue_kernel<T, M, SRC>, 64, dyn);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 32) per_cu = 32;
     uint64_t grid = (uint64_t)per_cu * (uint64_t)cached_cus;
     if (grid > npx * npy) grid = npx * npy;
-    hipLaunchKernelGGL((escape_queue_kernel<T, M, SRC>), dim3((uint32_t)grid), dim3(64), dyn, stream, p, out, (uint32_t)npx,
-                       (uint32_t)(npx * npy));
+    if (SRC == 1 && !p.second_v1) /* the survivor lists' own kernel; second_v1: round 2's (comparison only) */
+        hipLaunchKernelGGL((escape_second_kernel<T, M>), dim3((uint32_t)grid), dim3(64), dyn, stream, p, out);
+    else
+        hipLaunchKernelGGL((escape_queue_kernel<T, M, SRC>), dim3((uint32_t)grid), dim3(64), dyn, stream, p, out, (uint32_t)npx,
+                           (uint32_t)(npx * npy));
     return hipGetLastError();
 }
 
@@ -2668,7 +3091,7 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 template <typename T>
 hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream,
                             const char *&name) {
-    if (p.out_in_place && tile > 13) tile = 0; /* only the strip kernels know in-place addressing */
+    if (p.out_in_place && tile > 14) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
         name = FR_KNAME("escape_kernel", "64x1");
@@ -2690,7 +3113,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             /* Julia views are mostly short orbits with a heavy tail: two passes (see escape_first_kernel; the
              * host asks for it from 65 536 tiles up: fr_wants_two_pass) */
             name = p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
-                                : FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+                                : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
             return launch_two_pass<T>(p, out, stream);
         }
         if (tiles >= 262144) {
@@ -2725,13 +3148,15 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
                 return launch_two_pass<T>(p, out, stream, true);
             }
             name = p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
-                                : FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+                                : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
             return launch_two_pass<T>(p, out, stream);
         }
         [[fallthrough]];
-    case 11: /* two passes: strips to first_cap, then the work-queue kernel over the survivors (otherwise as 9) */
+    case 14: /* two passes with round 2's second-pass kernel (comparison only) */
+    case 11: /* two passes: strips to first_cap, then persistent waves over the survivors (otherwise as 9) */
         if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
-            name = FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            name = tile == 14 ? FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then round 2's persistent waves over the survivor lists")
+                              : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
             return launch_two_pass<T>(p, out, stream);
         }
         if (p.algo != 0 && p.algo != 2) {
@@ -2987,7 +3412,7 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint) {
         p.first_only = hint == 2 ? 1u : 0u;
     } else if (tile == 13) {
         p.first_only = 1u;
-    } else if (tile != 11 && tile != 12) {
+    } else if (tile != 11 && tile != 12 && tile != 14) {
         return false;
     }
     /* first_cap: a multiple of the loop's block length; the second pass must have something left to do */

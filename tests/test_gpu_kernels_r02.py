@@ -218,6 +218,12 @@ def test_two_pass_render_matches_the_oracle(fr, lib, case):
         for kw in (dict(cycle_shortcut=1), dict(colour_filter=0), dict(palette=0)):
             got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=11, **kw))
             assert np.array_equal(got, want), (case, prec, kw)
+        # the comparison variants: 12 = round 2's two kernels, 14 = round 2's second pass behind this round's first;
+        # second-pass policies (through tile 10's numbers the second pass keeps its own defaults: RGBA and row bands below)
+        for tile in (12, 14):
+            for episode, keep16 in ((-1, -1), (8, 16), (200, 8)):
+                got = fr.get_image_rows(cfg, 0, h, prec, opts=fr.RenderOpts(tile=tile, refill_minrun=episode, refill_quit16=keep16))
+                assert np.array_equal(got, want), (case, prec, tile, episode, keep16)
         try:  # lists of 64 entries each: nearly everything overflows and is finished by the first pass itself
             lib.fr_debug_set_two_pass_capacity(64)
             for episode in (-1, 8):
@@ -282,7 +288,7 @@ def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, l
     assert np.array_equal(img, fr.get_image_rows(cfg, 0, 5000, 0, opts=fr.RenderOpts(tile=8)))
 
 
-@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("tile", [10, 11, 14])
 def test_work_queue_kernel_row_bands_rgba_and_in_place_blocks(fr, lib, tile):
     import torch
     from fractal_renderer_amd import _native
@@ -359,8 +365,8 @@ def test_full_size_c4_work_queue_kernel(fr, lib, prec_name):
     assert gpu_total == total  # the executed-iteration sum of the whole image, CPU vs device
     assert torch.equal(view[1:, 1:], torch.flip(view[1:, 1:], dims=(0, 1)))
     # the default dispatch for an image like this: two passes; the patch-refill kernel; both with the filter off
-    for kw, kernel in ((dict(), b"escape_first_kernel + escape_queue_kernel"), (dict(tile=9), b"escape_refill_kernel"), (dict(tile=13), b"escape_first_kernel<"),
-                       (dict(tile=11, refill_minrun=128, refill_quit16=16), b"escape_first_kernel + escape_queue_kernel"),
+    for kw, kernel in ((dict(), b"escape_first_kernel + escape_second_kernel"), (dict(tile=9), b"escape_refill_kernel"), (dict(tile=13), b"escape_first_kernel<"),
+                       (dict(tile=11, refill_minrun=128, refill_quit16=16), b"escape_first_kernel + escape_second_kernel"),
                        (dict(colour_filter=0), b"escape_first_kernel"), (dict(tile=10, colour_filter=0), b"escape_queue_kernel")):
         other, name_o = render(**kw)
         assert name_o.startswith(kernel), (kw, name_o)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """C4 (Julia 16384^2 i=4096) kernel time of kernel variants, interleaved so that clock drift hits them alike.
-Usage (GPU box): python tools/c4_ab.py [tiles...]   default: 11 12   (11 = two passes, 12 = with round 2's first pass)
+Usage (GPU box): python tools/c4_ab.py [tiles...]   default: 11 14 12   (11 = two passes, 14 = with round 2's second pass,
+12 = with round 2's two kernels, 13 = the first pass alone)
 Prints per precision: best / median ms per variant (HIP events around the launch) and whether bytes agree."""
 import ctypes as C
 import os
@@ -13,7 +14,7 @@ sys.path.insert(0, ROOT)
 import fractal_renderer_amd as fr  # noqa: E402
 from fractal_renderer_amd import _native  # noqa: E402
 
-tiles = [int(a) for a in sys.argv[1:]] or [11, 12]
+tiles = [int(a) for a in sys.argv[1:]] or [11, 14, 12]
 fr.init(0)
 lib = _native.load()
 lib.fr_set_profiling(1)
