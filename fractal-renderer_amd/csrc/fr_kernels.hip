@@ -1195,12 +1195,10 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
  * boolean to an integer and compares it again, two vector instructions */
 __device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
-/* bit `lane` of a wave-uniform mask, as a per-lane boolean */
-__device__ __forceinline__ bool lane_in(unsigned long long m) {
-    uint32_t b;
-    asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(b) : "s"(m));
-    return b != 0u;
-}
+/* bit `lane` of a wave-uniform mask, as a per-lane boolean: a lane mask in scalar registers IS the machine's form of a
+ * per-lane boolean, and the builtin says so to the compiler — no instruction at all, where v_cndmask + v_cmp (two or
+ * three vector instructions per use) made one from the mask */
+__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 /* Blocks of M unchecked scaled iterations for the lanes of `mask` (a subset of EXEC, not empty), one |z|^2 <= T
  * test per block: a lane that fails it freezes with the state and t = A + B it has at that moment, and its count is
