@@ -2626,13 +2626,18 @@ __global__ __launch_bounds__(64) void escape_second_kernel(const fr_kparams p, c
     static_assert(FR_SURV_QUEUES == 64 && FR_SURV_CHUNK == 64, "one list counter per lane; a chunk is loaded one entry per lane");
     typedef typename Pair<T>::type T2;
     typedef typename UBits<T>::type UB;
-    /* the open chunk, converted: (X, Y), 2c (Mandelbrot), {count as f32 bits, output column, output row, count} */
-    __shared__ T2 s_cxy[FR_SURV_CHUNK], s_cc2[FR_SURV_CHUNK];
+    /* the open chunk, converted: (X, Y), {count as f32 bits, output column, output row, count} */
+    __shared__ T2 s_cxy[FR_SURV_CHUNK];
     __shared__ uint4 s_cmeta[FR_SURV_CHUNK];
     /* the stack of unfinished results, in the same form */
-    __shared__ T2 q_xy[kQStack], q_c2[kQStack];
+    __shared__ T2 q_xy[kQStack];
     __shared__ uint4 q_meta[kQStack];
-    extern __shared__ uint32_t s_dyn_palette[]; /* smooth == false: the palette, staged once */
+    /* dynamic: 2c of the chunk's and the stack's entries — Mandelbrot only: a Julia render's c is one constant, and the
+     * 3 KB (f64) they would take are three more resident waves per CU — then the palette (smooth == false), staged once */
+    extern __shared__ uint4 s_dyn[];
+    T2 *const s_cc2 = reinterpret_cast<T2 *>(s_dyn);
+    T2 *const q_c2 = s_cc2 + FR_SURV_CHUNK;
+    uint32_t *const s_dyn_palette = reinterpret_cast<uint32_t *>(s_dyn) + (p.algo == 2 ? 0u : (uint32_t)((FR_SURV_CHUNK + kQStack) * sizeof(T2) / 4));
     const uint32_t lane = threadIdx.x;
     const uint32_t *s_pal = nullptr;
     if (p.palette != nullptr) {
@@ -2964,7 +2969,8 @@ hipError_t launch_queue_form(const fr_kparams &p, const fr_kout &out, hipStream_
     const uint64_t npy = SRC == 1 ? FR_SURV_QUEUES : ((uint64_t)p.nrows + kQPatchH - 1) / kQPatchH;
     if (npx * npy == 0) return hipSuccess;
     if (npx * npy > 0xFFF00000ull) return hipErrorInvalidConfiguration; /* the counter overshoots by one per wave */
-    const size_t dyn = p.palette ? sizeof(uint32_t) * p.palette_entries : 0;
+    size_t dyn = p.palette ? sizeof(uint32_t) * p.palette_entries : 0;
+    if (SRC == 1 && !p.second_v1 && p.algo != 2) dyn += (FR_SURV_CHUNK + kQStack) * (sizeof(T) * 2); /* escape_second_kernel: 2c per entry */
     /* persistent grid: as many one-wave workgroups as the device holds at once (the occupancy query ignores
      * the SGPR budget and can answer a few too many per CU; harmless: a late workgroup finds the counter
      * exhausted and leaves) */

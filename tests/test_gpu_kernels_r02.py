@@ -577,3 +577,36 @@ def test_view_sample_statistics_match_the_oracles_escape_counts(fr, lib, prec_na
         got = dict(sum=st[0], mx=st[1], tiles=st[2], capped=st[3], handed=st[4], waste=st[5], rest=st[7])
         assert {k: int(v) for k, v in got.items()} == tot, (prec_name, algo, kw)
         assert st[6] == pytest.approx(tot["sum"] / tot["mx"])
+
+
+def test_two_pass_kernels_past_four_gigabytes_of_output(fr, lib):
+    """A device-pointer render whose image is larger than 4 GiB (36 000 x 40 000 x 3 = 4.32 GB): the first pass and the
+    second pass then address pixels with 64-bit arithmetic instead of a scalar base + 32-bit lane offset (`narrow` in
+    escape_first_kernel / escape_second_kernel) — a path no host-buffer render reaches (its bands are 64 MiB).  Two passes
+    (11), the first pass alone (13) and round 2's second pass (14) against the strip kernel (8), on the device."""
+    import torch
+    from fractal_renderer_amd import _native
+
+    w, h = 40000, 36000
+    ocfg = O.cli_config(w, h, O.JULIA, julia_set=(-0.8, 0.156), iterations=120)
+    cfg = to_fr(fr, ocfg)
+    need = 3 * w * h
+    assert need > 2 ** 32
+    s = torch.cuda.current_stream()
+
+    def render(tile):
+        d = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        o = fr.RenderOpts(tile=tile)
+        _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfg), 0, 0, h, d.data_ptr(), need, s.cuda_stream, C.byref(o)))
+        torch.cuda.synchronize()
+        return d
+
+    ref = render(8)
+    # rows of the reference against the oracle: the first, one in the middle, the last (offsets past 2^32)
+    got = ref.view(h, w, 3)
+    for y in (0, h // 2 + 1, h - 1):
+        assert np.array_equal(got[y].cpu().numpy(), O.get_image(ocfg, O.F64, y, y + 1)[0]), y
+    for tile in (11, 13, 14):
+        d = render(tile)
+        assert torch.equal(d, ref), tile
+        del d
