@@ -394,8 +394,9 @@ int fr_set_loop_mode(int mode);
  * which = 5: the packed form of the cast ((float)in[k] into byte 1 of the word 0xAABBCCDD, returned whole);
  * which = 6: the number of f32 bit patterns in [in[0], in[1]] on which the packed and the plain cast differ. */
 int fr_debug_math(int which, const double *in, double *out, size_t n);
-/* Tuning aid: a device buffer of 16 uint64 per persistent wave (8192 waves is enough) to which the work-queue
- * kernel's waves write their start / end times (100 MHz ticks) and work counts; NULL turns it off. */
+/* Tuning aid: a device buffer of 16 uint64 per persistent wave (8192 waves is enough) to which the waves of the
+ * persistent kernels (tile 10; the second pass of 11 / 12 / 14) write their start / end times (100 MHz ticks) and
+ * work counts (round 2's kernel also the cycles per phase); NULL turns it off. */
 int fr_debug_set_queue_trace(void *d_trace);
 /* Test aid: entries per survivor list of the two-pass render (tile 11); 0 = sized from the image.  A tiny
  * value makes the lists overflow, which the first pass absorbs by finishing those pixels itself. */

@@ -61,6 +61,9 @@ ph = {"open patch": t6 & np.uint64(0xFFFFFFFF), "refill": t6 >> np.uint64(32), "
       "retire (incl. finishing)": t7 >> np.uint64(32), "finishing + colour": t[:, 8].astype(np.uint64)}
 act = t[:, 2] > 0
 tot = sum(v[act].astype(np.float64).sum() for k, v in ph.items() if k != "finishing + colour")
+if tot == 0:  # escape_second_kernel (the survivor lists' own kernel, round 3) records no phase cycles; tile 14 / 10 do
+    print("(this kernel records no phase cycles)")
+    ph = {}
 for k, v in ph.items():
     x = v[act].astype(np.float64)
     print("%-26s %6.1f %% of phase cycles, median per wave %.0f" % (k, 100.0 * x.sum() / tot, np.median(x)))
