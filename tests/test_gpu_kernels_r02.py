@@ -610,3 +610,12 @@ def test_two_pass_kernels_past_four_gigabytes_of_output(fr, lib):
         d = render(tile)
         assert torch.equal(d, ref), tile
         del d
+    # RGBA8 (5.76 GB): one dword per pixel through the same 64-bit addressing
+    d = torch.empty(4 * w * h, dtype=torch.uint8, device="cuda:0")
+    o = fr.RenderOpts(tile=11)
+    _native.check(lib.fr_render_rows_rgba8_device_opts(C.byref(cfg), 0, 0, h, d.data_ptr(), d.numel(), s.cuda_stream, C.byref(o)))
+    torch.cuda.synchronize()
+    rgba = d.view(h, w, 4)
+    for y0 in range(0, h, 4000):  # in slabs: a strided comparison of the whole image would copy it
+        assert torch.equal(rgba[y0:y0 + 4000, :, :3], got[y0:y0 + 4000]), y0
+        assert bool((rgba[y0:y0 + 4000, :, 3] == 255).all()), y0
