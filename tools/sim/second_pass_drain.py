@@ -66,7 +66,12 @@ while active.any() and done < cap:
 # ---- remaining length of every handed-over orbit: blocks of M until |z|^2 > T (then ~5 exact iterations, not counted
 # here: they run in the finishing pass at full lanes) or the cap
 ex, ey = X[handed], Y[handed]
+ez2 = (ex * ex + ey * ey).astype(np.float64)  # |z|^2 at the hand-over
 ecnt = cnt[handed]
+# what the tile's other lanes did: the mean count of the lanes that had left by then (they froze at their count)
+gone = ~handed & ~run
+tile_gone_mean = np.where(gone.any(axis=1), (cnt * gone).sum(axis=1) / np.maximum(gone.sum(axis=1), 1), 0.0)
+egone = np.repeat(tile_gone_mean[:, None], 64, axis=1)[handed]
 elive = np.repeat(live_at[:, None], 64, axis=1)[handed]
 n = ex.size
 rem = np.zeros(n, np.int32)
@@ -137,6 +142,12 @@ longf = np.argsort(-(rem.astype(np.int64)), kind="stable")
 report("long first (oracle)", rem[longf])
 pred = np.argsort(-(elive[perm].astype(np.int64)), kind="stable")
 report("by live lanes at hand-over", rem[perm][pred])
+for pname, key in (("by |z|^2 at hand-over (small first)", ez2[perm]), ("by |z|^2 (large first)", -ez2[perm]),
+                   ("by count at hand-over (large first)", -ecnt[perm].astype(np.float64)),
+                   ("by the tile's gone lanes' mean count (large first)", -egone[perm])):
+    report(pname[:28], rem[perm][np.argsort(key, kind="stable")])
+print("rank correlation with the remaining length: |z|^2 %.3f, count %.3f, gone lanes' mean count %.3f, live lanes %.3f" % tuple(
+    float(np.corrcoef(np.argsort(np.argsort(v)), np.argsort(np.argsort(rem)))[0, 1]) for v in (ez2, ecnt, egone, elive)))
 for K in (128, 256, 512):
     short = np.minimum(rem[perm], K)
     over = rem[perm][rem[perm] > K] - K
