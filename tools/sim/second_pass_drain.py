@@ -207,3 +207,30 @@ for want in (4, 8, 12, 16, 24, 32, 48):
             eps += b
         print("want %2d minrun %2d: %7.1f wave-iterations, %5.2f episodes per 64 entries; lane use %.1f %%" % (
             want, minrun, tot * 64.0 / sample.size, eps * 64.0 / sample.size, 100.0 * float(sample.sum()) / (tot * 64.0)))
+
+# ---- cascaded lists, honestly: every level is the same refill kernel (want 24) with its own cap; what is still going at a
+#      level's cap is written to the next level's lists in the order it finishes there (taken as shuffled)
+print("\ncascades (every level the refill kernel, want 24, minrun 8):")
+def run_levels(caps):
+    cur = rem[perm].astype(np.int64)
+    tot_w = 0
+    desc = []
+    for K in caps:
+        run_len = np.minimum(cur, K) if K else cur
+        nw = max(1, len(run_len) // PER_WAVE)
+        tw = 0
+        for w in range(nw):
+            a, _ = drain_count(run_len[w::nw], 24, 8)
+            tw += a
+        tot_w += tw
+        desc.append("%s: %d entries, lane use %.1f %%" % ("cap %d" % K if K else "rest", len(cur), 100.0 * float(run_len.sum()) / (tw * 64.0)))
+        if not K:
+            break
+        cur = cur[cur > K] - K
+        cur = cur[rng.permutation(len(cur))]
+        if len(cur) == 0:
+            break
+    return tot_w, desc
+for caps in ((0,), (128, 0), (256, 0), (128, 512, 0), (64, 256, 1024, 0), (32, 64, 128, 256, 512, 1024, 0)):
+    tw, desc = run_levels(caps)
+    print("levels %-28s lane use overall %.1f %%   [%s]" % (str(caps), 100.0 * float(rem.sum()) / (tw * 64.0), "; ".join(desc)))
