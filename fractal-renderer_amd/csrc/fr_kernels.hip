@@ -711,6 +711,136 @@ __device__ __forceinline__ void store_pixel(const fr_kparams &p, uint8_t *base, 
     store_pixel(p.ncols, p.out_rgba, base, row, col, rgb);
 }
 
+/* Kernel arguments for the COLD parts of a kernel whose hot loop needs the scalar registers: re-read from
+ * the kernel-argument segment where they are used (scalar loads through a pointer the optimiser cannot see
+ * through) instead of being held in SGPRs from the kernel's entry on, as arguments normally are — the ~50
+ * values of the colour map and the addressing overflow the scalar file otherwise, and every use becomes a
+ * v_readlane spill reload (224 of them per tile in this kernel's first version). */
+typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
+#define FR_COLD_PARAMS(NAME)                                                          \
+    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is argument 0 */ \
+    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay where they are written */
+
+/* the lanes (of EXEC) with `b` set: the builtin on the i1 itself — s_and_b64 with EXEC; HIP's __ballot() converts the
+ * boolean to an integer and compares it again, two vector instructions */
+__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+/* bit `lane` of a wave-uniform mask, as a per-lane boolean: a lane mask in scalar registers IS the machine's form of a
+ * per-lane boolean, and the builtin says so to the compiler — no instruction at all, where v_cndmask + v_cmp (two or
+ * three vector instructions per use) made one from the mask */
+__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+/* The filter's first stage as the first pass evaluates it (same test, fewer instructions; constants fetched by
+ * tile_fast).  The three channels are p_k * m with ONE m, and the window of channel k is p_k * w with
+ *     w = |m| * 2^-20 + c,      c = |K| * E * (1 + 2^-9) rounded up     (p_k * c >= filt_d32[k], p_k >= 0),
+ * so both ends of all three windows come from two numbers, m - w and m + w.  The relative part is 2^-20 where
+ * colour_filter_stage1 has 2^-21: the ends here carry two more roundings (m -/+ w, then the fma), 2^-24 each, on
+ * top of the 2.4e-7 of m itself — 3.6e-7 against a window of 9.5e-7.  And the truncating cast of an end x is
+ * v_cvt_pk_u8_f32(x - 0.5), the -0.5 folded into the fma: round-to-nearest-even of x - 0.5 IS floor(x) unless x is
+ * an exact integer, where it may give x - 1; at the lower end that can only turn "decided" into "undecided", and at
+ * the upper end x - 1 is the right answer, because the true value lies STRICTLY inside the window (the slack above).
+ * Saturation and NaN as in sat_u8_pack.  Returns whether the byte triple is decided (then `lo` holds it). */
+struct Filter32 {
+    float lo, k, c, p0, p1, p2; /* channels in OUTPUT order (color_multiply's swap applied where this is filled) */
+};
+__device__ __forceinline__ uint32_t cvt_pk_u8_at(float v, uint32_t acc, int K) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, (uint32_t)K, acc); /* v_cvt_pk_u8_f32 (the builtin: no s_nop padding around it, as inline asm gets) */
+}
+__device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, float itp1, uint32_t &lo) {
+    const float l1 = __builtin_amdgcn_logf(d32);
+    const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
+    const float m = (itp1 - nu32) * f.k;
+    const float w = __builtin_fmaf(__builtin_fabsf(m), 0x1p-20f, f.c);
+    const float ml = m - w, mh = m + w;
+    lo = cvt_pk_u8_at(__builtin_fmaf(f.p2, ml, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p1, ml, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p0, ml, -0.5f), 0u, 0), 1), 2);
+    const uint32_t hi = cvt_pk_u8_at(__builtin_fmaf(f.p2, mh, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p1, mh, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p0, mh, -0.5f), 0u, 0), 1), 2);
+    return lo == hi;
+}
+
+/* one pixel per lane to `base + off` (a wave-uniform base in scalar registers, a 32-bit byte offset per lane: no
+ * vector address arithmetic): r,g,b as one 16-bit store — unaligned, as the compiler itself emits them on this
+ * target — plus the high byte of the same register, or r,g,b,255 as one dword.
+ * The s_nop: a memory instruction that reads a scalar register written by a VECTOR instruction needs five wait states
+ * on this target, and the compiler, which inserts them in its own code, does not look inside an asm statement: when
+ * it restores a spilled `base` with v_readlane right in front of this one, the store went out with the register's OLD
+ * upper half (escape_second_kernel<double>, round 3: "memory access fault", "beyond the largest legal address"). */
+__device__ __forceinline__ void store_packed(uint8_t *base, uint32_t off, uint32_t packed, uint32_t bpp) {
+    if (bpp == 4u) {
+        const uint32_t v = packed | 0xFF000000u;
+        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+    } else {
+        asm volatile("s_nop 4\n\tglobal_store_short %0, %1, %2\n\tglobal_store_byte_d16_hi %0, %1, %2 offset:2" : : "v"(off), "v"(packed), "s"(base) : "memory");
+    }
+}
+
+/* Where a strip kernel's tile goes, for the packed store: a wave-uniform base (the tile's first pixel) and one 32-bit
+ * byte offset per lane; fast_colour: the f32 stage of the colour filter applies to this render */
+struct TileOut {
+    uint8_t *base;
+    uint32_t lane_off, bpp;
+    bool narrow, fast_colour;
+};
+
+/* The colour of one pixel per lane, packed r | g << 8 | b << 16, decided PER LANE by the cheapest rule that proves its
+ * bytes (round 3; the strip kernel's colour map was 8 % of C2's instructions, as much again as the first pass's whole
+ * tile path):
+ *   1. dist surely outside (d32 >= filt_lo32, <= 2^120): the filter's f32 stage in the first pass's form (colour_fast32),
+ *      whatever the index — colour_of's first branch looks at dist alone (calc/src/lib.rs:216);
+ *   2. !(dist > stable_limit): the `inside` colour or black (:230-233) — the points of the set, a quarter of C2;
+ *   3. whatever is left (an undecided window, a dist between the two limits, a palette, no smoothing): colour_pixel.
+ * re / im / r2 / i2 / iters as colour_pixel takes them. */
+template <typename T>
+__device__ __forceinline__ uint32_t colour_packed(bool valid, bool fast_colour, T re, T im, T r2, T i2, uint32_t iters,
+                                                  const double *lds_tab, const uint32_t *palette) {
+    uint32_t packed = 0;
+    unsigned long long todo = ballot64(valid);
+    if (fast_colour) {
+        Filter32 f;
+        {
+            FR_COLD_PARAMS(kp);
+            f.lo = kp->filt_lo32, f.k = kp->filt_k32, f.c = kp->filt_c32;
+            f.p0 = kp->prim32[0], f.p1 = kp->prim32[2], f.p2 = kp->prim32[1]; /* colour_multiply's RGB::new(r, b, g) swap */
+        }
+        float d32;
+        if constexpr (sizeof(T) == 8)
+            d32 = (float)(r2 + i2);
+        else
+            d32 = r2 + i2; /* within 2^-23 of the reference's f64 sum: see colour_pixel */
+        uint32_t pk;
+        const bool decided = colour_fast32(f, d32, (float)(iters + 1u), pk); /* exact: iterations < 2^24 (the host checks) */
+        const bool ok = valid && d32 >= f.lo && d32 <= 0x1.ffffep119f && decided;
+        packed = ok ? pk : 0u;
+        todo &= ~ballot64(ok);
+    }
+    if (todo != 0ull) { /* wave-uniform */
+        bool inside_done = false;
+        if (lane_in(todo)) {
+            double dist;
+            if constexpr (sizeof(T) == 8) {
+                dist = (double)(r2 + i2);
+            } else {
+                const double zre = (double)re, zim = (double)im;
+                dist = zre * zre + zim * zim;
+            }
+            FR_COLD_PARAMS(kp);
+            inside_done = !(dist > kp->stable_limit);
+            if (inside_done && kp->inside) /* color_multiply(secondary_color, dist), with its RGB::new(r, b, g) swap */
+                packed = sat_u8_dev(kp->sec_f[0] * dist) | (sat_u8_dev(kp->sec_f[2] * dist) << 8) | (sat_u8_dev(kp->sec_f[1] * dist) << 16);
+        }
+        todo &= ~ballot64(inside_done);
+    }
+    if (todo != 0ull) {
+        if (lane_in(todo)) {
+            FR_COLD_PARAMS(kp);
+            const ColourConsts cc = make_colour_consts(*kp);
+            uint8_t rgb[3];
+            colour_pixel<T>(cc, re, im, r2, i2, iters, lds_tab, palette, rgb);
+            packed = (uint32_t)rgb[0] | ((uint32_t)rgb[1] << 8) | ((uint32_t)rgb[2] << 16);
+        }
+    }
+    return packed;
+}
+
 /* One pixel per lane, from its start coordinate to its output: orbit loop, then the colour map
  * (MODE RGB), the raw recursive() result (MODE ESCAPE) or the executed-iteration sum (MODE COUNT).
  * Every lane of the wave calls this together; `valid` masks lanes that fall outside the image. */
@@ -718,7 +848,7 @@ template <typename T, int MODE>
 __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout &out, const double *s_tab,
                                              const uint32_t *s_pal, double sre, double sim, bool valid,
                                              uint32_t cx, uint32_t r, uint32_t lane, uint32_t r_out,
-                                             int strip_scalable = -1) {
+                                             int strip_scalable = -1, const TileOut *to = nullptr) {
     double zre = 0.0, zim = 0.0;
     T tre = 0, tim = 0, tr2 = 0, ti2 = 0; /* the final position and its squares in the render's own type */
     uint32_t iters = 0;
@@ -744,7 +874,18 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
     }
 
     if constexpr (MODE == FR_OUT_RGB) {
-        if (valid) {
+        if (to != nullptr) { /* the strip kernel: per-lane colour rules, packed store (wave-uniform control up to the store) */
+            uint32_t packed = 0;
+            if (escape_algo) packed = colour_packed<T>(valid, to->fast_colour, tre, tim, tr2, ti2, iters, s_tab, s_pal);
+            if (valid) {
+                if (to->narrow) {
+                    store_packed(to->base, to->lane_off, packed, to->bpp);
+                } else {
+                    const uint8_t rgb[3] = {(uint8_t)packed, (uint8_t)(packed >> 8), (uint8_t)(packed >> 16)};
+                    store_pixel(p, out.rgb, r_out, cx, rgb);
+                }
+            }
+        } else if (valid) {
             uint8_t rgb[3] = {0, 0, 0};
             if (escape_algo) {
                 const ColourConsts cc = make_colour_consts(p);
@@ -905,6 +1046,13 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
     if (p.out_in_place) out_row0 = p.y_first + (row0 / p.block_rows) * p.y_stride + row0 % p.block_rows;
     const uint32_t r_out = out_row0 + ly;
     const int strip_scalable = (p.loop_mode != 0 && strip_is_scalable<T>(p, coord_lane, tile0, row0, lane)) ? 1 : 0;
+    /* RGB: where the strip's tiles go (a scalar base per tile + one 32-bit offset per lane, as in the first pass) */
+    TileOut to;
+    to.bpp = p.out_rgba ? 4u : 3u;
+    to.narrow = (uint64_t)p.ncols * to.bpp * 8u <= 0xFFFFFFFFull;
+    to.lane_off = ly * (p.ncols * to.bpp) + lx * to.bpp;
+    to.fast_colour = p.colour_filter32 && p.smooth && p.palette == nullptr;
+    uint8_t *const strip_base = MODE == FR_OUT_RGB ? out.rgb + ((uint64_t)out_row0 * p.ncols + (uint64_t)tile0 * 8u) * to.bpp : nullptr;
 
     for (int k = 0; k < kStripTiles; k++) {
         const uint32_t col0 = (tile0 + k) * 8u;
@@ -912,7 +1060,8 @@ __global__ __launch_bounds__(64) void escape_strip_kernel(const fr_kparams p, co
         const double sre = __shfl(coord_lane, k * 8 + lx, 64);
         const uint32_t cx = col0 + lx;
         const bool valid = cx < p.ncols && r < p.nrows;
-        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane, r_out, strip_scalable);
+        to.base = strip_base + (size_t)((uint32_t)k * 8u * to.bpp);
+        render_pixel<T, MODE>(p, out, s_tab, s_pal, sre, sim, valid, cx, r, lane, r_out, strip_scalable, MODE == FR_OUT_RGB ? &to : nullptr);
     }
 }
 
@@ -951,16 +1100,6 @@ template <>
 struct Pair<double> {
     typedef double2 type;
 };
-
-/* Kernel arguments for the COLD parts of a kernel whose hot loop needs the scalar registers: re-read from
- * the kernel-argument segment where they are used (scalar loads through a pointer the optimiser cannot see
- * through) instead of being held in SGPRs from the kernel's entry on, as arguments normally are — the ~50
- * values of the colour map and the addressing overflow the scalar file otherwise, and every use becomes a
- * v_readlane spill reload (224 of them per tile in this kernel's first version). */
-typedef const __attribute__((address_space(4))) fr_kparams *KArgs;
-#define FR_COLD_PARAMS(NAME)                                                          \
-    KArgs NAME = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is argument 0 */ \
-    asm volatile("" : "+s"(NAME)) /* opaque: the loads through it stay where they are written */
 
 /* is this coordinate admissible as a start / c component of the scaled loop?  (see lane_is_scalable) */
 template <typename T>
@@ -1190,15 +1329,6 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
         return (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v));
     }
 }
-
-/* the lanes (of EXEC) with `b` set: the builtin on the i1 itself — s_and_b64 with EXEC; HIP's __ballot() converts the
- * boolean to an integer and compares it again, two vector instructions */
-__device__ __forceinline__ unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
-
-/* bit `lane` of a wave-uniform mask, as a per-lane boolean: a lane mask in scalar registers IS the machine's form of a
- * per-lane boolean, and the builtin says so to the compiler — no instruction at all, where v_cndmask + v_cmp (two or
- * three vector instructions per use) made one from the mask */
-__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 /* Blocks of M unchecked scaled iterations for the lanes of `mask` (a subset of EXEC, not empty), one |z|^2 <= T
  * test per block: a lane that fails it freezes with the state and t = A + B it has at that moment, and its count is
@@ -1436,49 +1566,6 @@ __device__ __forceinline__ uint32_t tile_fast(uint32_t nblk, T sre, T Y0, T B0, 
             asm volatile(FR_TILE_ASM("f32", "v_mov_b32", FR_SC_IT("f32"), "2.0") FR_TILE_OPERANDS);
     }
     return st;
-}
-
-/* The filter's first stage as the first pass evaluates it (same test, fewer instructions; constants fetched by
- * tile_fast).  The three channels are p_k * m with ONE m, and the window of channel k is p_k * w with
- *     w = |m| * 2^-20 + c,      c = |K| * E * (1 + 2^-9) rounded up     (p_k * c >= filt_d32[k], p_k >= 0),
- * so both ends of all three windows come from two numbers, m - w and m + w.  The relative part is 2^-20 where
- * colour_filter_stage1 has 2^-21: the ends here carry two more roundings (m -/+ w, then the fma), 2^-24 each, on
- * top of the 2.4e-7 of m itself — 3.6e-7 against a window of 9.5e-7.  And the truncating cast of an end x is
- * v_cvt_pk_u8_f32(x - 0.5), the -0.5 folded into the fma: round-to-nearest-even of x - 0.5 IS floor(x) unless x is
- * an exact integer, where it may give x - 1; at the lower end that can only turn "decided" into "undecided", and at
- * the upper end x - 1 is the right answer, because the true value lies STRICTLY inside the window (the slack above).
- * Saturation and NaN as in sat_u8_pack.  Returns whether the byte triple is decided (then `lo` holds it). */
-struct Filter32 {
-    float lo, k, c, p0, p1, p2; /* channels in OUTPUT order (color_multiply's swap applied where this is filled) */
-};
-__device__ __forceinline__ uint32_t cvt_pk_u8_at(float v, uint32_t acc, int K) {
-    return __builtin_amdgcn_cvt_pk_u8_f32(v, (uint32_t)K, acc); /* v_cvt_pk_u8_f32 (the builtin: no s_nop padding around it, as inline asm gets) */
-}
-__device__ __forceinline__ bool colour_fast32(const Filter32 &f, float d32, float itp1, uint32_t &lo) {
-    const float l1 = __builtin_amdgcn_logf(d32);
-    const float nu32 = __builtin_amdgcn_logf(l1 * 0.25f);
-    const float m = (itp1 - nu32) * f.k;
-    const float w = __builtin_fmaf(__builtin_fabsf(m), 0x1p-20f, f.c);
-    const float ml = m - w, mh = m + w;
-    lo = cvt_pk_u8_at(__builtin_fmaf(f.p2, ml, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p1, ml, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p0, ml, -0.5f), 0u, 0), 1), 2);
-    const uint32_t hi = cvt_pk_u8_at(__builtin_fmaf(f.p2, mh, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p1, mh, -0.5f), cvt_pk_u8_at(__builtin_fmaf(f.p0, mh, -0.5f), 0u, 0), 1), 2);
-    return lo == hi;
-}
-
-/* one pixel per lane to `base + off` (a wave-uniform base in scalar registers, a 32-bit byte offset per lane: no
- * vector address arithmetic): r,g,b as one 16-bit store — unaligned, as the compiler itself emits them on this
- * target — plus the high byte of the same register, or r,g,b,255 as one dword.
- * The s_nop: a memory instruction that reads a scalar register written by a VECTOR instruction needs five wait states
- * on this target, and the compiler, which inserts them in its own code, does not look inside an asm statement: when
- * it restores a spilled `base` with v_readlane right in front of this one, the store went out with the register's OLD
- * upper half (escape_second_kernel<double>, round 3: "memory access fault", "beyond the largest legal address"). */
-__device__ __forceinline__ void store_packed(uint8_t *base, uint32_t off, uint32_t packed, uint32_t bpp) {
-    if (bpp == 4u) {
-        const uint32_t v = packed | 0xFF000000u;
-        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
-    } else {
-        asm volatile("s_nop 4\n\tglobal_store_short %0, %1, %2\n\tglobal_store_byte_d16_hi %0, %1, %2 offset:2" : : "v"(off), "v"(packed), "s"(base) : "memory");
-    }
 }
 
 /* ds_bpermute of a T (lane `byte_index / 4`'s value), the index a ready-made byte offset */
