@@ -1,24 +1,38 @@
-import sys, os, time
-sys.path.insert(0, "/root/repo")
-import numpy as np
-import fractal_renderer_amd as fr
+#!/usr/bin/env python3
+"""The drop-in pattern of the reference's GUI (src/gui.rs:56-82): every redraw gets a FRESH buffer from get_image and drops
+it after the upload.  Times 100 such calls per frame size through the host-buffer entry point (kernel + D2H + call), the
+buffer touched before the call, and 100 calls into one buffer that stays.  FR_TRACE=1 adds the library's own timeline.
+Usage (GPU box): python tools/first_large_frame.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import fractal_renderer_amd as fr  # noqa: E402
+
 fr.init(0)
-def call(w, h, it, tag, ch=3, tile=None):
+for w, h in ((750, 500), (1920, 1080), (3840, 2160), (5000, 3000)):
     cfg = fr.Config.new()
-    cfg.width, cfg.height, cfg.iterations = w, h, it
-    buf = np.zeros((h, w, ch), dtype=np.uint8); buf.fill(1)
-    t0 = time.perf_counter()
-    if ch == 3:
+    cfg.width, cfg.height, cfg.iterations = w, h, 1024
+    keep = np.ones((h, w, 3), dtype=np.uint8)
+    fr.get_image_rows(cfg, 0, h, fr.Precision.F64, out=keep)
+    same, fresh, lib_fresh = [], [], []
+    for _ in range(100):
+        t0 = time.perf_counter()
+        fr.get_image_rows(cfg, 0, h, fr.Precision.F64, out=keep)
+        same.append((time.perf_counter() - t0) * 1e3)
+    for _ in range(100):
+        buf = np.empty((h, w, 3), dtype=np.uint8)
+        buf.fill(1)
+        t0 = time.perf_counter()
         fr.get_image_rows(cfg, 0, h, fr.Precision.F64, out=buf)
-    else:
-        fr.get_image_rgba(cfg, fr.Precision.F64, out=buf)
-    print("%s %dx%d: %.3f ms" % (tag, w, h, (time.perf_counter() - t0) * 1e3), flush=True)
-call(750, 500, 50, "warm small")
-call(1920, 1080, 1024, "1080p")
-call(2600, 1500, 1024, "11.7 MB")
-call(2800, 1700, 1024, "14.3 MB")
-call(3000, 1900, 1024, "17.1 MB")
-call(3840, 2160, 1024, "4K first")
-call(3840, 2160, 1024, "4K second (new buffer)")
-call(5000, 3000, 1024, "45 MB")
-call(5000, 3000, 1024, "45 MB again")
+        fresh.append((time.perf_counter() - t0) * 1e3)
+        del buf
+    for _ in range(100):
+        t0 = time.perf_counter()
+        img = fr.get_image(cfg)  # the library's own fresh buffer (untouched pages: first touch inside the call)
+        lib_fresh.append((time.perf_counter() - t0) * 1e3)
+        del img
+    f = lambda v: "min %.2f med %.2f max %.2f" % (min(v), sorted(v)[len(v) // 2], max(v))
+    print("%dx%d (%.1f MB): same buffer %s | fresh touched buffer per call %s | get_image() %s" % (w, h, 3e-6 * w * h, f(same), f(fresh), f(lib_fresh)), flush=True)
