@@ -11,7 +11,6 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -21,7 +20,6 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "fr_ctx.h"
@@ -577,21 +575,6 @@ static uint64_t view_key(const fr_config *cfg, const fr_kparams &p, int precisio
     return h ? h : 1;
 }
 
-hipError_t wait_stream(hipStream_t stream) {
-    using clock = std::chrono::steady_clock;
-    const clock::time_point t0 = clock::now();
-    bool polled = false;
-    for (;;) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e != hipErrorNotReady) {
-            if (polled) (void)hipGetLastError(); /* a "not ready" answer must not surface as the next launch's error */
-            return e;
-        }
-        polled = true;
-        if (clock::now() - t0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-    }
-}
-
 int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[7]) {
     std::lock_guard<std::mutex> lk(ctx.sample_mu);
     void *d_result = nullptr;
@@ -599,7 +582,7 @@ int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[7]) {
     const uint32_t cap_s = p.iterations < kSampleCap ? p.iterations : kSampleCap;
     HIP_TRY(fr_launch_view_sample(p, precision, 16, cap_s, 64, 48, ctx.sample_counters, static_cast<unsigned long long *>(d_result),
                                   ctx.aux_stream));
-    HIP_TRY(wait_stream(ctx.aux_stream));
+    HIP_TRY(hipStreamSynchronize(ctx.aux_stream));
     for (int k = 0; k < 7; k++) out[k] = (double)__atomic_load_n(ctx.sample_result + k, __ATOMIC_RELAXED);
     return FR_OK;
 }

@@ -141,13 +141,6 @@ int render_block_cyclic(Ctx &ctx, const fr_config *cfg, int precision, const Opt
 
 int check_precision(int precision);
 
-/* Wait for everything queued on `stream` — by polling (hipStreamQuery: a read of the queue's completion signal, ~1 us),
- * not by hipStreamSynchronize: its interrupt-driven wake-up has been seen to come ~25 ms AFTER the GPU's own events had
- * the last copy done — about one call in sixty when the caller hands a fresh buffer per frame, as the reference's GUI
- * does (profiles/r03_gui_fresh_buffer_pattern.txt), in the staged-copy path and the pinned one alike — and a GUI frame is
- * a millisecond.  Spins for the first 2 ms (GUI frames end within that), then polls every 50 us (C2's 17 ms call: +0.3 %). */
-hipError_t wait_stream(hipStream_t stream);
-
 /* choose_kernel for rows [y0, y1) of the image as ONE launch, recorded in `o` (tile 0 only): callers that render those
  * rows in several launches then sample the view once, not once per launch.  The calling thread must be on ctx's device. */
 void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o);

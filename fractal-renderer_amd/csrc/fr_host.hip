@@ -239,7 +239,7 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
         rc = render_on(ctx.stream, y0, y1, scratch);
         if (rc != FR_OK) return rc;
         HIP_TRY(hipMemcpyAsync(out, scratch, need, hipMemcpyDeviceToHost, ctx.stream));
-        HIP_TRY(wait_stream(ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
         return FR_OK;
     }
 
@@ -349,10 +349,10 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     }
     const double t_enqueued = now_ms();
     /* always drain both streams and unpin before returning, error or not */
-    hipError_t e1 = wait_stream(ctx.stream);
-    const hipError_t e1b = wait_stream(ctx.stream2);
+    hipError_t e1 = hipStreamSynchronize(ctx.stream);
+    const hipError_t e1b = hipStreamSynchronize(ctx.stream2);
     if (e1 == hipSuccess) e1 = e1b;
-    hipError_t e2 = wait_stream(ctx.copy_stream);
+    hipError_t e2 = hipStreamSynchronize(ctx.copy_stream);
     const double t_synced = now_ms();
     pinner.release();
     if (trace)
@@ -381,8 +381,8 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     }
     if (rc != FR_OK) return rc;
     if (err != hipSuccess) return fail_hip(err, what);
-    if (e1 != hipSuccess) return fail_hip(e1, "wait_stream(stream)");
-    if (e2 != hipSuccess) return fail_hip(e2, "wait_stream(copy_stream)");
+    if (e1 != hipSuccess) return fail_hip(e1, "hipStreamSynchronize(stream)");
+    if (e2 != hipSuccess) return fail_hip(e2, "hipStreamSynchronize(copy_stream)");
     return FR_OK;
 }
 
