@@ -157,6 +157,15 @@ int Ctx::create(int device) {
         HIP_TRY(hipEventCreateWithFlags(&palette_slots[k].done, hipEventDisableTiming));
     }
     for (SurvSlot &ss : surv_slots) HIP_TRY(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
+    /* ... and the survivor-list ring for every frame up to 3840 x 2160 (one entry per eight pixels, at most 44 bytes each:
+     * 46 MB a slot), so that a GUI's first large Julia frame does not wait ~15 ms for the allocation (acquire_surv re-makes
+     * the ring only for a launch that needs more) */
+    {
+        constexpr size_t kGuiSlot = (size_t)48 << 20;
+        HIP_TRY(hipMalloc(&surv_block, kGuiSlot * kSurvSlots));
+        surv_slot_cap = kGuiSlot;
+        for (int k = 0; k < kSurvSlots; k++) surv_slots[k].dev = static_cast<char *>(surv_block) + (size_t)k * kGuiSlot;
+    }
     hip_device = device;
     /* the host-buffer entry points' device image buffer: room for a 3840 x 2160 RGBA frame from the start, so that a GUI's
      * first frames (src/gui.rs:56-82) do not pay for its growth (a 4K first frame: 2.5-3.4 ms against 0.7-0.9 steady) */

@@ -73,9 +73,9 @@ struct PaletteSlot {
 constexpr int kPaletteSlots = 16;
 
 /* Survivor lists of the two-pass render (fr_kernels.hip): a ring of three buffers cut from ONE device allocation
- * (Ctx::surv_block), made when the first launch that needs lists arrives and re-made only for a launch that needs more
- * than a slot holds — the one allocation the device-pointer entry points can block on (first large two-pass frame,
- * or a larger one than any before); handed out like the palette slots. */
+ * (Ctx::surv_block), made with the context for frames up to 3840 x 2160 and re-made only for a launch that needs more
+ * than a slot holds — the one allocation the device-pointer entry points can block on (a larger two-pass frame than
+ * any before); handed out like the palette slots. */
 struct SurvSlot {
     void *dev = nullptr;
     hipEvent_t done = nullptr;

@@ -327,9 +327,9 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
  *      persistent waves of a second kernel then finish.  Same conditions as 10 (otherwise it acts as 9).  The
  *      lists live in a context-owned ring of three buffers cut from one allocation: per entry 20 bytes (f32 Julia),
  *      28 (f64 Julia; f32 Mandelbrot), 44 (f64 Mandelbrot), one entry per eight pixels of the launch (at most 2^28
- *      entries) — C4 in f32: 671 MB per buffer, 2 GB for the ring.  The ring is allocated when the first launch that
- *      needs lists arrives and re-allocated only for a launch that needs more: the one allocation a device-pointer
- *      render can block on (~15 ms, once).  A list that is full costs speed only;
+ *      entries) — C4 in f32: 671 MB per buffer, 2 GB for the ring.  The ring exists from the context's creation on
+ *      for frames up to 3840 x 2160 (3 x 48 MiB) and is re-allocated only for a launch that needs more: the one allocation
+ *      a device-pointer render can block on (~15 ms, once per size never seen before).  A list that is full costs speed only;
  * 12 = two passes with round 2's two kernels (kept for comparisons: tools/c4_ab.py);
  * 13 = the first pass of 11 alone: no tile is handed over (every lane finishes in place), no lists, no second kernel;
  * 14 = 11 with round 2's second-pass kernel behind this round's first pass (kept for comparisons);
