@@ -138,6 +138,8 @@ PROTOTYPES = {
     "fr_debug_rccl_probe": (C.c_int, []),
     "fr_set_dispatch_sampling": (C.c_int, [C.c_int]),
     "fr_debug_sample_view": (C.c_int, [C.POINTER(fr_config), C.c_int, C.POINTER(C.c_double)]),
+    "fr_debug_view_choice": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "fr_debug_inject_multi_failure": (C.c_int, [C.c_int, C.c_int]),
     "fr_pin_host_buffer": (C.c_int, [C.c_void_p, C.c_size_t]),
     "fr_unpin_host_buffer": (C.c_int, [C.c_void_p]),

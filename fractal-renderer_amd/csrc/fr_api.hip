@@ -55,7 +55,7 @@ std::atomic<uint32_t> g_two_pass_list_entries{0};          /* test aid, see fr_d
 
 bool valid_tile(int tile) {
     switch (tile) {
-    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 6401: case 3202: case 1604: case 808:
+    case 0: case 1: case 2: case 4: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 6401: case 3202: case 1604: case 808:
         return true;
     default:
         return false;
@@ -115,7 +115,7 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     o = default_opts();
     if (!in) return FR_OK;
     if (in->size < sizeof(fr_render_opts)) return fail(FR_ERR_INVALID_ARGUMENT, "fr_render_opts.size is too small (use fr_render_opts_init)");
-    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 6401, 3202, 1604 or 808");
+    if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10 ... 16, 6401, 3202, 1604 or 808");
     if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
         return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
     if (in->refill_minrun < -1 || in->refill_quit16 < -1 || in->refill_quit16 == 0 || in->refill_quit16 > 16)
@@ -134,6 +134,7 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
 
 int Ctx::create(int device) {
     HIP_TRY(hipSetDevice(device));
+    hip_device = device; /* from here on destroy() releases whatever the steps below managed to create */
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     /* D2H and peer copies of registered memory run as shader (blit) kernels on this runtime: give their
@@ -146,9 +147,12 @@ int Ctx::create(int device) {
     }
     HIP_TRY(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_greatest));
     HIP_TRY(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, prio_greatest));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sample_counters), 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(sample_counters, 0, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sample_result), 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    HIP_TRY(hipStreamCreateWithPriority(&aux2_stream, hipStreamNonBlocking, prio_least));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sample_counters), 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sample_counters, 0, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sample_result), (kViewChoices + 1) * 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(sample_result, 0, (kViewChoices + 1) * 8 * sizeof(unsigned long long));
+    for (ViewChoice &v : view_choices) HIP_TRY(hipEventCreateWithFlags(&v.after, hipEventDisableTiming));
     /* every palette / claim-counter slot and every ring event now, so that no render allocates them on its way */
     constexpr size_t kSlotWords = FR_MAX_PALETTE_ENTRIES + FR_SURV_QUEUES * FR_SURV_COUNT_STRIDE;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&palette_block), sizeof(uint32_t) * kSlotWords * kPaletteSlots));
@@ -157,19 +161,28 @@ int Ctx::create(int device) {
         HIP_TRY(hipEventCreateWithFlags(&palette_slots[k].done, hipEventDisableTiming));
     }
     for (SurvSlot &ss : surv_slots) HIP_TRY(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
-    /* ... and the survivor-list ring for every frame up to 3840 x 2160 (one entry per eight pixels, at most 44 bytes each:
-     * 46 MB a slot), so that a GUI's first large Julia frame does not wait ~15 ms for the allocation (acquire_surv re-makes
-     * the ring only for a launch that needs more) */
+    /* ... and, BEST EFFORT, the survivor-list ring for every frame up to 3840 x 2160 (one entry per eight pixels, at most 44
+     * bytes each: 46 MB a slot), so that a GUI's first large Julia frame does not wait ~15 ms for the allocation
+     * (acquire_surv re-makes the ring only for a launch that needs more), and the host-buffer entry points' device image
+     * buffer with room for a 3840 x 2160 RGBA frame (a 4K first frame: 2.5-3.4 ms against 0.7-0.9 steady).  On a device too
+     * full for these ~210 MB the context is still made: both grow lazily (acquire_surv, reserve) when a render needs them. */
     {
         constexpr size_t kGuiSlot = (size_t)48 << 20;
-        HIP_TRY(hipMalloc(&surv_block, kGuiSlot * kSurvSlots));
-        surv_slot_cap = kGuiSlot;
-        for (int k = 0; k < kSurvSlots; k++) surv_slots[k].dev = static_cast<char *>(surv_block) + (size_t)k * kGuiSlot;
+        if (hipMalloc(&surv_block, kGuiSlot * kSurvSlots) == hipSuccess) {
+            surv_slot_cap = kGuiSlot;
+            for (int k = 0; k < kSurvSlots; k++) surv_slots[k].dev = static_cast<char *>(surv_block) + (size_t)k * kGuiSlot;
+        } else {
+            (void)hipGetLastError();
+            surv_block = nullptr;
+        }
+        if (hipMalloc(&rgb.ptr, (size_t)64 << 20) == hipSuccess) {
+            rgb.cap = (size_t)64 << 20;
+        } else {
+            (void)hipGetLastError();
+            rgb = Scratch();
+        }
     }
-    hip_device = device;
-    /* the host-buffer entry points' device image buffer: room for a 3840 x 2160 RGBA frame from the start, so that a GUI's
-     * first frames (src/gui.rs:56-82) do not pay for its growth (a 4K first frame: 2.5-3.4 ms against 0.7-0.9 steady) */
-    return reserve(rgb, (size_t)64 << 20);
+    return FR_OK;
 }
 
 void Ctx::destroy() {
@@ -197,11 +210,16 @@ void Ctx::destroy() {
     }
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
+    for (hipStream_t *st : {&aux_stream, &aux2_stream})
+        if (*st) (void)hipStreamSynchronize(*st); /* a sample in flight writes to sample_result */
     if (sample_counters) (void)hipFree(sample_counters);
     if (sample_result) (void)hipHostFree(sample_result);
     sample_counters = sample_result = nullptr;
-    for (ViewChoice &v : view_choices) v = ViewChoice();
-    for (hipStream_t *st : {&stream, &stream2, &copy_stream, &aux_stream}) {
+    for (ViewChoice &v : view_choices) {
+        if (v.after) (void)hipEventDestroy(v.after);
+        v = ViewChoice();
+    }
+    for (hipStream_t *st : {&stream, &stream2, &copy_stream, &aux_stream, &aux2_stream}) {
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
@@ -258,7 +276,7 @@ int Ctx::acquire_palette(PaletteSlot **out) {
             std::lock_guard<std::mutex> lk(palette_mu);
             s->busy = false;
         }
-        slot_cv.notify_one();
+        slot_cv.notify_all(); /* (waiters of both rings share the condition variable) */
         return fail_hip(e, "palette slot");
     }
     *out = s;
@@ -275,7 +293,7 @@ void Ctx::release_palette(PaletteSlot *slot, hipStream_t st) {
         slot->pending = recorded;
         slot->busy = false;
     }
-    slot_cv.notify_one();
+    slot_cv.notify_all(); /* (waiters of both rings share the condition variable) */
 }
 
 int Ctx::acquire_surv(size_t bytes, SurvSlot **out) {
@@ -284,39 +302,62 @@ int Ctx::acquire_surv(size_t bytes, SurvSlot **out) {
     hipError_t e = hipSuccess;
     {
         std::unique_lock<std::mutex> lk(palette_mu);
-        if (surv_slot_cap < bytes) {
-            /* the ring is (re)made in one allocation: wait until nobody is between acquire and release, wait for the
-             * renders that used the old buffers, then free and allocate — the one blocking allocation of the render
-             * path (the first launch that needs lists, or one that needs larger lists than any before) */
-            slot_cv.wait(lk, [&] {
-                for (const SurvSlot &c : surv_slots)
-                    if (c.busy) return false;
-                return true;
-            });
-            if (surv_slot_cap < bytes) { /* (another thread may have grown it meanwhile) */
-                for (SurvSlot &c : surv_slots) {
-                    if (c.pending && e == hipSuccess) e = hipEventSynchronize(c.done);
-                    c.pending = false;
-                    c.dev = nullptr;
-                }
-                if (surv_block && e == hipSuccess) e = hipFree(surv_block);
-                surv_block = nullptr, surv_slot_cap = 0;
-                const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-                if (e == hipSuccess) e = hipMalloc(&surv_block, cap * kSurvSlots);
-                if (e != hipSuccess) {
-                    surv_block = nullptr;
-                    return fail_hip(e, "survivor-list ring");
-                }
-                surv_slot_cap = cap;
-                for (int k = 0; k < kSurvSlots; k++) surv_slots[k].dev = static_cast<char *>(surv_block) + (size_t)k * cap;
+        for (;;) {
+            if (surv_regrowing) {
+                slot_cv.wait(lk);
+                continue;
             }
-        }
-        while (!s) {
-            for (int tries = 0; tries < kSurvSlots && !s; tries++) {
-                SurvSlot &c = surv_slots[surv_next++ % kSurvSlots];
-                if (!c.busy) s = &c;
+            if (surv_slot_cap >= bytes) {
+                for (int tries = 0; tries < kSurvSlots && !s; tries++) {
+                    SurvSlot &c = surv_slots[surv_next++ % kSurvSlots];
+                    if (!c.busy) s = &c;
+                }
+                if (s) break;
+                slot_cv.wait(lk); /* more renders being enqueued at once than there are buffers */
+                continue;
             }
-            if (!s) slot_cv.wait(lk); /* more renders being enqueued at once than there are buffers */
+            /* The ring is (re)made in one allocation — the one blocking allocation of the render path (the first launch
+             * that needs lists larger than any before).  One thread does it, with the lock DROPPED over the waits, the
+             * free and the malloc (hipFree is a device-wide synchronisation, the malloc may be gigabytes): palette slots
+             * keep circulating meanwhile; other callers that need lists sleep until the ring is republished. */
+            bool someone_busy = false;
+            for (const SurvSlot &c : surv_slots) someone_busy = someone_busy || c.busy;
+            if (someone_busy) {
+                slot_cv.wait(lk);
+                continue;
+            }
+            surv_regrowing = true;
+            void *old = surv_block;
+            bool was_pending[kSurvSlots];
+            for (int k = 0; k < kSurvSlots; k++) {
+                was_pending[k] = surv_slots[k].pending;
+                surv_slots[k].pending = false;
+                surv_slots[k].dev = nullptr;
+            }
+            surv_block = nullptr, surv_slot_cap = 0;
+            lk.unlock();
+            for (int k = 0; k < kSurvSlots; k++) /* the renders that used the old buffers */
+                if (was_pending[k]) {
+                    const hipError_t se = hipEventSynchronize(surv_slots[k].done);
+                    if (e == hipSuccess) e = se;
+                }
+            if (old) { /* freed whatever the waits said (hipFree itself waits for the device): nothing leaks on an error path */
+                const hipError_t fe = hipFree(old);
+                if (e == hipSuccess) e = fe;
+            }
+            const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+            void *blk = nullptr;
+            if (e == hipSuccess) e = hipMalloc(&blk, cap * kSurvSlots);
+            lk.lock();
+            surv_regrowing = false;
+            if (e != hipSuccess) { /* the ring is empty (capacity 0): the next launch that needs lists tries again */
+                lk.unlock();
+                slot_cv.notify_all();
+                return fail_hip(e, "survivor-list ring");
+            }
+            surv_block = blk, surv_slot_cap = cap;
+            for (int k = 0; k < kSurvSlots; k++) surv_slots[k].dev = static_cast<char *>(surv_block) + (size_t)k * cap;
+            slot_cv.notify_all();
         }
         s->busy = true;
         pending = s->pending;
@@ -434,12 +475,12 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
      * once 24 lanes are free and 8 iterations were done */
     p.refill_minrun = o.refill_minrun < 0 ? 32u : (uint32_t)o.refill_minrun;
     p.refill_quit16 = o.refill_quit16 < 0 ? 8u : (uint32_t)o.refill_quit16;
-    p.queue_minrun = (o.refill_minrun < 0 || (o.tile >= 11 && o.tile <= 14)) ? 8u : (uint32_t)o.refill_minrun;
+    p.queue_minrun = (o.refill_minrun < 0 || (o.tile >= 11 && o.tile <= 16)) ? 8u : (uint32_t)o.refill_minrun;
     /* tile 11: minrun = the first pass's episode length, quit16 = the lanes (in 16ths of a wave) a tile must
      * keep running to stay in the first pass; the second pass keeps its own defaults */
-    p.first_keep = ((o.tile >= 11 && o.tile <= 14) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
-    p.two_pass_cap = ((o.tile >= 11 && o.tile <= 14) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
-    p.queue_want = (o.refill_quit16 < 0 || (o.tile >= 11 && o.tile <= 14)) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
+    p.first_keep = ((o.tile >= 11 && o.tile <= 16) && o.refill_quit16 > 0) ? 4u * (uint32_t)o.refill_quit16 : 0u;
+    p.two_pass_cap = ((o.tile >= 11 && o.tile <= 16) && o.refill_minrun > 0) ? (uint32_t)o.refill_minrun : 0u; /* tile 11: minrun = first_cap */
+    p.queue_want = (o.refill_quit16 < 0 || (o.tile >= 11 && o.tile <= 16)) ? 24u : (64u * (uint32_t)o.refill_quit16 + 15u) / 16u;
     {
         /* tuning aid: the second pass's own policy under the two-pass render (whose fr_set_refill_policy numbers
          * steer the first pass): FR_DEBUG_QUEUE_WANT / FR_DEBUG_QUEUE_MINRUN */
@@ -552,24 +593,33 @@ int check_precision(int precision) {
 
 std::atomic<int> g_dispatch_sampling{1};
 
-/* Which kernel for a large launch?  Decided from the IMAGE, not from the algorithm's name.  A sample of 16 x 16 tiles
- * of the launch goes through the plain loop (view_sample_kernel; ~20-70 us, on a stream of the library's own so that
- * it never waits behind the caller's queue) and tells, for the tiles it saw:
+/* Which kernel for a launch?  Decided from the IMAGE, not from the algorithm's name.  A sample of 16 x 16 tiles of the
+ * launch goes through the plain loop (view_sample_kernel; ~20-70 us of device time) and tells, for the tiles it saw:
  *   capped    the share of pixels still running at the sample's cap (interior, or deep boundary);
- *   waste     the lane-iterations that finishing the stragglers of thinned-out tiles IN PLACE would idle away, as a
- *             share of the work — what the two-pass render's lists exist to save;
- *   mean      executed iterations per pixel (x pixels / the first pass's rate = an estimate of the render's time).
- * Three kernels (measured on 13 views x 2 precisions, tools/two_pass_views.py, profiles/r03_kernel_choice_views.txt):
+ *   handed    the share of pixels the first pass's own episode schedule would hand over to the survivor lists;
+ *   waste     the lane-iterations that finishing those stragglers IN PLACE would idle away, as a share of the work —
+ *             what the two-pass render's lists exist to save;
+ *   mean      executed iterations per pixel.
+ * Three kernel families (measured on 13 views x 2 precisions, tools/two_pass_views.py; profiles/r03_kernel_choice_views.txt
+ * for 8192^2, profiles/r04_kernel_choice_midsize.txt for 2048^2 and 3840 x 2160):
  *   two passes        taken when the first pass's schedule would hand over at least one pixel in 500;
- *   first pass alone  (7-tile strips in episodes, frozen lanes finished once per tile, nothing handed over): 10-13 % ahead
- *                     of the strip kernel on views of short orbits, level with it on long ones;
+ *   first pass alone  (strips in episodes, frozen lanes finished once per tile, nothing handed over): 10-13 % ahead of the
+ *                     strip kernel on views of short orbits, level with it on long ones;
  *   strips            1-3 % ahead on interior-heavy views (its loop is 6.5 vector instructions per iteration from the first).
- * Only for launches large enough for the answer to matter and the sample to be cheap beside them; the last few (view,
- * launch) pairs are remembered, so re-rendering a view — a GUI changing colours (src/gui.rs:183-203), bench.py's
- * steps — samples once.  Returns 1 two passes, 2 first pass alone, 0 strips, -1 no opinion.  This is the one
- * host-blocking step of the device-pointer entry points (first frame of a new view, images of 4096 x 2048 pixels and
- * more); fr_set_dispatch_sampling(0) removes it. */
+ * WHEN the sample is taken depends on the launch:
+ *   >= 131 072 tiles (4096 x 2048): BLOCKING, in front of the first launch of a view (40 us beside a render of milliseconds;
+ *      the one host-blocking step of the device-pointer entry points; fr_set_dispatch_sampling(0) removes it);
+ *   4096 .. 131 072 tiles (every frame a GUI asks for, src/gui.rs:56-82): NON-BLOCKING.  The first frame of a view is
+ *      dispatched as before (by algorithm and size) and the sample is enqueued BEHIND its render on a stream of the
+ *      library's own; the totals land in host-mapped memory, the view's key last.  The next frame of the same view — what
+ *      every slider move re-requests — finds them and is dispatched from measured numbers.  Nothing waits, ever: a frame
+ *      that comes before the totals goes by name once more.
+ * The key hashes exactly the fields that determine ORBITS (algo, size, cap, limit, pos, scale, julia_set, the launch's grid,
+ * the precision): a GUI changing colours, exposure, smooth or inside (src/gui.rs:183-203) keeps its view.  The last 32
+ * views are remembered.  No sample while the caller's stream is being captured into a graph (neither a host wait nor a
+ * cross-stream event belongs in a capture).  Returns 1 two passes, 2 first pass alone, 0 strips, -1 no opinion. */
 constexpr uint64_t kSampleMinTiles = 131072;
+constexpr uint64_t kAsyncMinTiles = 4096;
 constexpr uint32_t kSampleCap = 4096;
 
 static uint64_t view_key(const fr_config *cfg, const fr_kparams &p, int precision) {
@@ -578,65 +628,157 @@ static uint64_t view_key(const fr_config *cfg, const fr_kparams &p, int precisio
         const unsigned char *b = static_cast<const unsigned char *>(data);
         for (size_t k = 0; k < n; k++) h = (h ^ b[k]) * 1099511628211ull;
     };
-    mix(cfg, sizeof *cfg);
+    /* field by field: no padding bytes (indeterminate in a caller-built struct), nothing the colour map alone reads */
+    const uint32_t ints[4] = {cfg->algo, cfg->width, cfg->height, cfg->iterations};
+    const double reals[7] = {cfg->limit, cfg->pos.re, cfg->pos.im, cfg->scale.re, cfg->scale.im, cfg->julia_set.re, cfg->julia_set.im};
+    mix(ints, sizeof ints);
+    mix(reals, sizeof reals);
     const uint32_t grid[8] = {p.ncols, p.nrows, p.x_first, p.x_stride, p.block_rows, p.y_first, p.y_stride, (uint32_t)precision};
     mix(grid, sizeof grid);
     return h ? h : 1;
 }
 
-int sample_view(Ctx &ctx, const fr_kparams &p, int precision, double out[7]) {
+/* blocking sample into result set `set` (kViewChoices = the debug hook's own) */
+int sample_view(Ctx &ctx, const fr_kparams &p, int precision, int set, double out[7]) {
     std::lock_guard<std::mutex> lk(ctx.sample_mu);
     void *d_result = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_result, ctx.sample_result, 0));
+    unsigned long long *res = ctx.sample_result + 8 * set;
     const uint32_t cap_s = p.iterations < kSampleCap ? p.iterations : kSampleCap;
-    HIP_TRY(fr_launch_view_sample(p, precision, 16, cap_s, 64, 48, ctx.sample_counters, static_cast<unsigned long long *>(d_result),
+    HIP_TRY(fr_launch_view_sample(p, precision, 16, cap_s, 64, 48, ctx.sample_counters, static_cast<unsigned long long *>(d_result) + 8 * set, 0ull,
                                   ctx.aux_stream));
     HIP_TRY(hipStreamSynchronize(ctx.aux_stream));
-    for (int k = 0; k < 7; k++) out[k] = (double)__atomic_load_n(ctx.sample_result + k, __ATOMIC_RELAXED);
+    for (int k = 0; k < 7; k++) out[k] = (double)__atomic_load_n(res + k, __ATOMIC_RELAXED);
     return FR_OK;
 }
 
-static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, int precision, const Opts &o, bool *one_band) {
+struct Decision {
+    int choice;
+    bool one_band;
+    uint32_t strip_tiles;
+};
+
+static Decision decide_from_sample(const double st[7], uint64_t tiles, const fr_kparams &p, int precision) {
+    const double lanes = 64.0 * st[2];
+    const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes, handed = st[4] / lanes;
+    Decision d{2, false, 0u};
+    if (tiles >= kSampleMinTiles) {
+        if (capped >= 0.10 && waste < 0.01)
+            d.choice = 0; /* long orbits dominate and tiles stay full: the strip kernel's ground */
+        else if (handed >= 0.002 || (handed * (double)p.ncols * (double)p.nrows >= 4096.0 && st[6] >= 128.0 * st[4]))
+            d.choice = 1; /* thinned-out tiles would hand over at least one pixel in 500 — or fewer, but thousands of them with long
+                           * tails (128 iterations and more to go, on average): finished in place those are a few workgroups' serial
+                           * chains, in the lists they spread over the chip — the lists pay (measured from 131 072-tile
+                           * launches up; an estimate of the idle time saved against the second pass's cost was tried as the
+                           * criterion and mispredicted wide launches, whose second pass costs next to nothing) */
+        else
+            d.choice = 2;
+        /* long orbits: workgroups of four strips (28 tiles) differ too much in cost to balance over the chip — C2 through
+         * the first pass alone: 14.2 ms with four strips per workgroup, strips 13.3 (tools/c2c3_choice.py) */
+        d.one_band = mean >= 128.0;
+        return d;
+    }
+    /* GUI-sized launches (profiles/r04_kernel_choice_midsize.txt) */
+    (void)precision;
+    if (handed >= 0.05 && waste >= 0.5) {
+        d.choice = 1; /* a dust: most tiles thin out early and their stragglers are long — the lists pay even here */
+        d.strip_tiles = 4;
+    } else if (mean < 32.0) {
+        d.choice = 2; /* short orbits: the first pass's per-tile overhead is a third of the strip kernel's */
+        d.strip_tiles = 4;
+    } else {
+        d.choice = 0; /* strips, their length by launch size as before */
+    }
+    return d;
+}
+
+void Ctx::post_sample(int idx, hipStream_t stream) {
+    if (idx < 0 || idx >= kViewChoices) return;
+    std::lock_guard<std::mutex> lk(sample_mu);
+    ViewChoice &v = view_choices[idx];
+    if (v.state != 1) return;
+    void *d_result = nullptr;
+    const uint32_t cap_s = v.grid.iterations < kSampleCap ? v.grid.iterations : kSampleCap;
+    const bool ok = hipHostGetDevicePointer(&d_result, sample_result, 0) == hipSuccess &&
+                    hipEventRecord(v.after, stream) == hipSuccess && hipStreamWaitEvent(aux2_stream, v.after, 0) == hipSuccess &&
+                    fr_launch_view_sample(v.grid, v.precision, 16, cap_s, 64, 48, sample_counters + 8,
+                                          static_cast<unsigned long long *>(d_result) + 8 * idx, v.key, aux2_stream) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        v.state = 0, v.key = 0; /* the slot is free again; the view goes by name */
+    }
+}
+
+static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, int precision, const Opts &o, hipStream_t stream,
+                         bool allow_async, bool *one_band, uint32_t *strip_tiles, int *pending) {
     *one_band = false;
+    *strip_tiles = 0;
+    *pending = -1;
     if (o.tile != 0 || !g_dispatch_sampling.load()) return -1;
     const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
-    if (tiles < kSampleMinTiles) return -1;
+    if (tiles < kAsyncMinTiles) return -1;
     fr_kparams q = p; /* would two passes be possible at all? */
     if (!fr_wants_two_pass(q, precision, 0, 1)) return -1;
     const uint64_t key = view_key(cfg, p, precision);
+    int slot_idx = -1;
     {
         std::lock_guard<std::mutex> lk(ctx.sample_mu);
-        for (const Ctx::ViewChoice &v : ctx.view_choices)
-            if (v.key == key) {
-                *one_band = v.one_band;
-                return v.two_pass;
+        for (int k = 0; k < Ctx::kViewChoices; k++) {
+            Ctx::ViewChoice &v = ctx.view_choices[k];
+            if (v.key != key || v.state == 0) continue;
+            if (v.state == 1) {
+                /* a sample is in flight: are its totals there?  (the kernel writes the key LAST) */
+                const unsigned long long *res = ctx.sample_result + 8 * k;
+                if (__atomic_load_n(res + 7, __ATOMIC_ACQUIRE) != key) return -1; /* not yet: by name once more */
+                double st[7];
+                for (int j = 0; j < 7; j++) st[j] = (double)__atomic_load_n(res + j, __ATOMIC_RELAXED);
+                if (st[1] <= 0.0 || st[0] <= 0.0) {
+                    v.state = 2, v.two_pass = -1;
+                } else {
+                    const Decision d = decide_from_sample(st, tiles, p, precision);
+                    v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles;
+                    v.lane_fraction = st[0] / st[1];
+                }
             }
+            *one_band = v.one_band;
+            *strip_tiles = v.strip_tiles;
+            return v.two_pass;
+        }
+        /* a view not seen before.  No sample of either kind while the caller's stream is being captured */
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+        if (cs != hipStreamCaptureStatusNone) return -1;
+        if (tiles < kSampleMinTiles && !allow_async) return -1;
+        slot_idx = (int)(ctx.view_next++ % Ctx::kViewChoices);
+        Ctx::ViewChoice &v = ctx.view_choices[slot_idx];
+        hipEvent_t ev = v.after;
+        v = Ctx::ViewChoice();
+        v.after = ev;
+        v.key = key, v.state = 1, v.grid = p, v.precision = precision;
+        __atomic_store_n(ctx.sample_result + 8 * slot_idx + 7, 0ull, __ATOMIC_RELEASE);
+        if (tiles < kSampleMinTiles) {
+            *pending = slot_idx; /* the caller posts it behind its render (Ctx::post_sample) */
+            return -1;
+        }
     }
     double st[7];
-    if (sample_view(ctx, p, precision, st) != FR_OK || st[1] <= 0.0) return -1; /* no opinion rather than a failed render */
-    const double lanes = 64.0 * st[2];
-    const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes, handed = st[4] / lanes;
-    int choice;
-    if (capped >= 0.10 && waste < 0.01)
-        choice = 0; /* long orbits dominate and tiles stay full: the strip kernel's ground */
-    else if (handed >= 0.002 || (handed * (double)p.ncols * (double)p.nrows >= 4096.0 && st[6] >= 128.0 * st[4]))
-        choice = 1; /* thinned-out tiles would hand over at least one pixel in 500 — or fewer, but thousands of them with long
-                     * tails (128 iterations and more to go, on average): finished in place those are a few workgroups' serial
-                     * chains, in the lists they spread over the chip — the lists pay (measured from 131 072-tile
-                     * launches up; an estimate of the idle time saved against the second pass's cost was tried as the
-                     * criterion and mispredicted wide launches, whose second pass costs next to nothing) */
-    else
-        choice = 2;
+    const int rc = sample_view(ctx, p, precision, slot_idx, st);
     std::lock_guard<std::mutex> lk(ctx.sample_mu);
-    Ctx::ViewChoice &slot = ctx.view_choices[ctx.view_next++ % Ctx::kViewChoices];
-    /* long orbits: workgroups of four strips (28 tiles) differ too much in cost to balance over the chip — C2 through
-     * the first pass alone: 14.2 ms with four strips per workgroup, strips 13.3 (tools/c2c3_choice.py) */
-    *one_band = mean >= 128.0;
-    slot.key = key, slot.two_pass = choice, slot.lane_fraction = st[0] / st[1], slot.one_band = *one_band;
-    return choice;
+    Ctx::ViewChoice &v = ctx.view_choices[slot_idx];
+    if (v.key != key || v.state != 1) return -1; /* (the slot was recycled meanwhile: 32 other new views) */
+    if (rc != FR_OK || st[1] <= 0.0 || st[0] <= 0.0) { /* no opinion rather than a failed render */
+        v.state = 0, v.key = 0;
+        return -1;
+    }
+    const Decision d = decide_from_sample(st, tiles, p, precision);
+    v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles, v.lane_fraction = st[0] / st[1];
+    *one_band = d.one_band;
+    *strip_tiles = d.strip_tiles;
+    return d.choice;
 }
 
-void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o) {
+void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o, hipStream_t stream,
+                   bool allow_async) {
     if (o.tile != 0 || o.kernel_hint != -2 || y1 <= y0 || cfg->width == 0) return;
     fr_kparams p;
     fill_params(cfg, o, p);
@@ -646,12 +788,17 @@ void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, u
     p.y_stride = 0;
     plan_loop(cfg, precision, o, p);
     bool one_band = false;
-    o.kernel_hint = choose_kernel(ctx, cfg, p, precision, o, &one_band);
+    uint32_t strip_tiles = 0;
+    int pending = -1;
+    o.kernel_hint = choose_kernel(ctx, cfg, p, precision, o, stream, allow_async, &one_band, &strip_tiles, &pending);
     o.one_band = one_band;
+    o.strip_tiles = strip_tiles;
+    o.pending_sample = pending;
 }
 
-/* device-pointer render of an arbitrary local grid; no host synchronisation, no shared scratch except
- * the palette slot `ctx` lends: re-entrant */
+/* device-pointer render of an arbitrary local grid; no shared scratch except the slots `ctx` lends: re-entrant.  Host
+ * synchronisation: none, with ONE exception — the first launch of a view of 131 072 tiles and more takes a blocking
+ * 40 us sample (choose_kernel; off under stream capture and with fr_set_dispatch_sampling(0)). */
 int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, const Opts &o, void *d_out,
                   hipStream_t stream) {
     plan_loop(cfg, precision, o, p);
@@ -660,10 +807,20 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
      * in LDS.  Larger palettes would cost occupancy; they are computed per pixel instead. */
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
-    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 14;
+    const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 16;
     bool one_band = o.one_band;
-    const int hint = o.kernel_hint != -2 ? o.kernel_hint : choose_kernel(ctx, cfg, p, precision, o, &one_band);
+    uint32_t strip_tiles = o.strip_tiles;
+    int pending = -1;
+    const int hint = o.kernel_hint != -2 ? o.kernel_hint
+                                         : choose_kernel(ctx, cfg, p, precision, o, stream, true, &one_band, &strip_tiles, &pending);
+    struct SampleGuard { /* whatever happens below, a slot that was promised a sample gets it (or is freed) */
+        Ctx &ctx;
+        int idx;
+        hipStream_t stream;
+        ~SampleGuard() { ctx.post_sample(idx, stream); }
+    } sample_guard{ctx, pending, stream};
     const bool want_two_pass = fr_wants_two_pass(p, precision, o.tile, hint);
+    if (o.tile == 0 && hint >= 0 && strip_tiles) p.strip_tiles = strip_tiles;
     p.first_one_band = one_band ? 1u : 0u;
     p.second_v1 = (o.tile == 12 || o.tile == 14) ? 1u : 0u; /* 12 = round 2's two kernels, 14 = its second pass behind this round's first */
     {
@@ -1252,7 +1409,7 @@ int fr_last_kernel_name(char *buf, size_t buf_len) {
 }
 
 int fr_set_tile(int tile) {
-    if (!valid_tile(tile)) return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 10, 11, 6401, 3202, 1604 or 808");
+    if (!valid_tile(tile)) return fail(FR_ERR_INVALID_ARGUMENT, "tile must be 0, 1, 2, 4, 8, 9, 10 ... 16, 6401, 3202, 1604 or 808");
     g_tile.store(tile);
     return FR_OK;
 }
@@ -1311,11 +1468,42 @@ int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]) {
     p.y_stride = 0;
     if (p.ncols == 0 || p.nrows == 0) return fail(FR_ERR_INVALID_ARGUMENT, "empty image");
     double st[7];
-    rc = sample_view(*ctx, p, precision, st);
+    rc = sample_view(*ctx, p, precision, Ctx::kViewChoices, st);
     if (rc != FR_OK) return rc;
     for (int k = 0; k < 6; k++) out[k] = st[k];
     out[6] = st[1] > 0.0 ? st[0] / st[1] : 0.0;
     out[7] = st[6];
+    return FR_OK;
+}
+
+int fr_debug_view_choice(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, int *state, int *choice,
+                         uint32_t *strip_tiles) {
+    if (!cfg || !state || !choice || !strip_tiles) return fail(FR_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_rows(cfg, y0, y1);
+    if (rc == FR_OK) rc = check_precision(precision);
+    if (rc != FR_OK) return rc;
+    LifeShared ls;
+    Ctx *ctx;
+    rc = primary(&ctx);
+    if (rc != FR_OK) return rc;
+    fr_kparams p;
+    fill_params(cfg, default_opts(), p);
+    p.nrows = y1 - y0;
+    p.y_first = y0;
+    p.block_rows = p.nrows ? p.nrows : 1;
+    p.y_stride = 0;
+    const uint64_t key = view_key(cfg, p, precision);
+    *state = 0, *choice = -1, *strip_tiles = 0;
+    std::lock_guard<std::mutex> lk(ctx->sample_mu);
+    for (int k = 0; k < Ctx::kViewChoices; k++) {
+        const Ctx::ViewChoice &v = ctx->view_choices[k];
+        if (v.key != key || v.state == 0) continue;
+        *state = v.state;
+        if (v.state == 1 && __atomic_load_n(ctx->sample_result + 8 * k + 7, __ATOMIC_ACQUIRE) == key) *state = 3; /* totals are in, not read yet */
+        *choice = v.two_pass;
+        *strip_tiles = v.strip_tiles;
+        break;
+    }
     return FR_OK;
 }
 

@@ -51,6 +51,9 @@ struct Opts {
      * one-strip-per-workgroup flag */
     int kernel_hint = -2;
     bool one_band = false;
+    uint32_t strip_tiles = 0; /* with kernel_hint >= 0: the strip length the view's statistics call for (0 = by launch size) */
+    /* a non-blocking view sample the caller still has to post BEHIND its render (Ctx::post_sample): slot index, -1 none */
+    int pending_sample = -1;
 };
 Opts default_opts();                             /* what the fr_set_* calls have set */
 int resolve_opts(const fr_render_opts *o, Opts &out); /* NULL = defaults; validates */
@@ -95,22 +98,34 @@ struct Ctx {
     SurvSlot surv_slots[kSurvSlots];
     void *surv_block = nullptr; /* kSurvSlots x surv_slot_cap bytes */
     size_t surv_slot_cap = 0;
+    bool surv_regrowing = false; /* a thread is re-making the ring with palette_mu dropped (acquire_surv) */
     uint32_t *palette_block = nullptr; /* kPaletteSlots slots, allocated with the context */
-    /* view sample (fr_api.hip: choose_kernel): a stream of its own — the sample must not wait behind whatever the
-     * caller has queued on its stream — five device counters, four host-mapped result words, a few remembered views */
-    hipStream_t aux_stream = nullptr;
-    unsigned long long *sample_counters = nullptr; /* device */
-    unsigned long long *sample_result = nullptr;   /* pinned host memory, mapped */
-    std::mutex sample_mu;
+    /* view samples (fr_api.hip: choose_kernel).  Large launches: a BLOCKING sample on aux_stream — a stream of its own: the
+     * sample must not wait behind whatever the caller has queued on its stream.  GUI-sized launches: a NON-BLOCKING one on
+     * aux2_stream, behind the render of the frame it was asked for (an event of the caller's stream), read by the NEXT
+     * frame of the same view.  Each has its own eight device counters; every remembered view its own eight result words
+     * (host-mapped; the kernel writes the view's key into the eighth LAST), plus one set for fr_debug_sample_view. */
+    hipStream_t aux_stream = nullptr, aux2_stream = nullptr;
+    unsigned long long *sample_counters = nullptr; /* device: 2 x 8 words */
+    unsigned long long *sample_result = nullptr;   /* pinned host memory, mapped: (kViewChoices + 1) x 8 words */
+    std::mutex sample_mu; /* the view table AND the order of launches on the two sample streams */
     struct ViewChoice {
         uint64_t key = 0;
-        int two_pass = -1;
+        int state = 0; /* 0 free, 1 a sample is (about to be) in flight, 2 decided */
+        int two_pass = -1; /* -1 no opinion, 0 strips, 1 two passes, 2 the first pass alone */
         bool one_band = false;
+        uint32_t strip_tiles = 0;
         double lane_fraction = 0.0;
+        fr_kparams grid; /* state 1: what the sample is launched with */
+        int precision = 0;
+        hipEvent_t after = nullptr; /* recorded on the caller's stream behind the render the sample follows */
     };
     static constexpr int kViewChoices = 32; /* (a rank of a multi-GPU run renders its share in up to a dozen chunk launches per image, each its own view) */
     ViewChoice view_choices[kViewChoices];
     unsigned view_next = 0;
+    /* enqueue slot `idx`'s sample behind everything `stream` holds now; never blocks, never fails the render (a sample that
+     * cannot be posted frees its slot) */
+    void post_sample(int idx, hipStream_t stream);
     std::mutex palette_mu; /* guards both rings */
     std::condition_variable slot_cv; /* a slot of either ring was released */
     unsigned palette_next = 0, surv_next = 0;
@@ -143,7 +158,8 @@ int check_precision(int precision);
 
 /* choose_kernel for rows [y0, y1) of the image as ONE launch, recorded in `o` (tile 0 only): callers that render those
  * rows in several launches then sample the view once, not once per launch.  The calling thread must be on ctx's device. */
-void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o);
+void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, Opts &o, hipStream_t stream,
+                   bool allow_async);
 
 /* the primary context (what fr_init selected); locks and lazily creates it.  Callers hold
  * `life_shared()` while they use it. */

@@ -246,7 +246,9 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
     /* 0. which kernel suits the view is decided ONCE, from a sample of all the rows (each band would otherwise take
      *    its own sample, blocking, in front of its launch) */
     Opts ob = o;
-    decide_kernel(ctx, cfg, precision, y0, y1, ob);
+    decide_kernel(ctx, cfg, precision, y0, y1, ob, ctx.stream, true);
+    const int pending_sample = ob.pending_sample; /* a first frame of a GUI-sized view: its sample goes behind the bands */
+    ob.pending_sample = -1;
     use_opts = &ob;
     /* 1. every band's kernel, enqueued up front: the GPU renders while the host prepares the buffer.  Bands
      *    are ~64 MiB of whole 8-row tiles (smaller over the last stretch) and alternate between two streams,
@@ -307,6 +309,7 @@ int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &
             }
         }
     }
+    ctx.post_sample(pending_sample, (order.size() & 1) ? ctx.stream : ctx.stream2); /* behind the LAST band enqueued */
     const double t_launched = now_ms();
 
     /* 2. the caller's buffer, band by band in the same order: first touch (a background thread, ahead of us)

@@ -88,6 +88,8 @@ struct fr_kparams {
     uint32_t second_v1;    /* 1: the survivor lists are drained by round 2's kernel, escape_queue_kernel<.., 1> (comparison only) */
     uint32_t first_one_band; /* 1: one 7-tile strip per workgroup whatever the launch size (views of long orbits: workgroups of
                               * 28 tiles differ too much in cost to balance) */
+    uint32_t strip_tiles; /* strip length asked for by the caller: first pass 4 (GUI-sized launches) else 7; strip kernel
+                           * (tile 0, RGB) 1 / 2 / 4 / 7, 0 = by launch size */
     uint32_t surv_sub_capacity;
     void *surv_z;           /* T[2] per entry: the position after first_cap iterations */
     uint32_t *surv_pos;     /* uint32[2] per entry: output column, output row */
@@ -142,11 +144,14 @@ struct fr_two_pass_layout {
 fr_two_pass_layout fr_two_pass_bytes(const fr_kparams &p, int precision, uint32_t sub_capacity);
 
 /* View sample (fr_kernels.hip: view_sample_kernel): side x side 8x8 tiles of the launch through the plain loop capped
- * at cap_s; the last wave writes {executed iterations, 64 x sum of per-tile maxima, tiles, lanes at the cap, lanes a first
- * episode of `episode` iterations would hand over (tiles with fewer than `keep` lanes left), lane-iterations wasted by
- * finishing those in place} to `result` (host-mapped) and zeroes `counters` (8 device words, zero before the first use). */
+ * at cap_s; the last wave writes SEVEN totals — {executed iterations, 64 x sum of per-tile maxima, tiles, lanes at the cap,
+ * lanes the first pass's episode schedule (`episode` iterations, doubling from the ninth on) would hand over (tiles with
+ * fewer than `keep` lanes left), lane-iterations wasted by finishing those in place, iterations the handed-over lanes still
+ * have to run} — to result[0..6] (host-mapped), then `tag` to result[7] (release: a host polling for the tag reads complete
+ * totals), and zeroes `counters` (8 device words, zero before the first use; one sample at a time per counter set). */
 hipError_t fr_launch_view_sample(const fr_kparams &p, int precision, uint32_t side, uint32_t cap_s, uint32_t episode, uint32_t keep,
-                                 unsigned long long *counters, unsigned long long *result, hipStream_t stream);
+                                 unsigned long long *counters, unsigned long long *result, unsigned long long tag,
+                                 hipStream_t stream);
 
 /* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
  * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */

@@ -3096,35 +3096,50 @@ hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t str
 
 /* Two passes, RGB output only; needs the survivor lists and p.work_counter (all counters zeroed on the launch
  * stream by the caller) and 0 < p.first_cap < p.iterations */
-template <typename T>
-hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream, bool v1 = false) {
-    if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
-    constexpr int kStripTiles = 7;
+template <typename T, int kStripTiles>
+hipError_t launch_first_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream, bool v1) {
     const uint64_t gx = ((uint64_t)p.ncols + 8 * kStripTiles - 1) / (8 * kStripTiles);
     const uint64_t row_tiles = ((uint64_t)p.nrows + 7) / 8;
     /* Four strips per workgroup share its fixed costs (-1.5 % on the 16384^2 C4 in f64) but leave a quarter of the
      * workgroups to balance over the chip: at 8192^2 (37 000 of them for 8192 resident waves) C4's dust takes 0.86 ms
      * instead of 0.72, and filled sets, whose workgroups differ a thousandfold in cost, lose more.  So: only while
-     * at least 131 072 workgroups remain. */
-    const int bands = (!p.first_one_band && gx * ((row_tiles + 3) / 4) >= 131072) ? 4 : 1;
+     * at least 131 072 workgroups remain (7-tile strips only: the short strips are for launches far below that). */
+    const int bands = (kStripTiles == 7 && !p.first_one_band && gx * ((row_tiles + 3) / 4) >= 131072) ? 4 : 1;
     const uint64_t row_blocks = (row_tiles + bands - 1) / bands;
     const uint64_t gy = row_blocks < 32768 ? row_blocks : 32768;
     const uint64_t gz = (row_blocks + gy - 1) / gy;
     if (gx > 0x7FFFFFFFull || gz > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
-    if (v1 && p.loop_mode == 4 && bands == 4) /* round 2's first pass, kept for comparison (tile 12) */
-        hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
-    else if (v1 && p.loop_mode == 4)
-        hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
-    else if (p.loop_mode == 4 && bands == 4)
-        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
-    else if (p.loop_mode == 4)
-        hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
-    else if (bands == 4)
-        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
-    else
-        hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
-    hipError_t e = hipGetLastError();
+    if constexpr (kStripTiles == 7) {
+        if (v1 && p.loop_mode == 4 && bands == 4) /* round 2's first pass, kept for comparison (tile 12) */
+            hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
+        else if (v1 && p.loop_mode == 4)
+            hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+        else if (p.loop_mode == 4 && bands == 4)
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
+        else if (p.loop_mode == 4)
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+        else if (bands == 4)
+            hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
+        else
+            hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+    } else {
+        if (p.loop_mode == 4)
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+        else
+            hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+    }
+    return hipGetLastError();
+}
+
+/* Two passes, RGB output only; needs the survivor lists and p.work_counter (all counters zeroed on the launch
+ * stream by the caller) and 0 < p.first_cap < p.iterations.  p.strip_tiles = 4: the first pass in 4-tile strips
+ * (GUI-sized launches: four times as many workgroups to balance over the chip), else 7. */
+template <typename T>
+hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t stream, bool v1 = false) {
+    if (p.ncols == 0 || p.nrows == 0) return hipSuccess;
+    const hipError_t e = (p.strip_tiles == 4 && !v1) ? launch_first_pass<T, 4>(p, out, stream, false)
+                                                           : launch_first_pass<T, 7>(p, out, stream, v1);
     if (e != hipSuccess) return e;
     if (p.first_only) return hipSuccess; /* nothing was handed over: there are no lists */
     if (p.loop_mode == 4) return launch_queue_form<T, 4, 1>(p, out, stream);
@@ -3180,9 +3195,18 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 #define FR_KNAME(base, k) (sizeof(T) == 8 ? base "<double, " k ">" : base "<float, " k ">")
 
 template <typename T>
+const char *first_pass_name(const fr_kparams &p) {
+    if (p.strip_tiles == 4)
+        return p.first_only ? FR_KNAME("escape_first_kernel", "4-tile strips in episodes, every tile finished in place")
+                            : FR_KNAME("escape_first_kernel + escape_second_kernel", "4-tile strips, then persistent waves over the survivor lists");
+    return p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
+                        : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
+}
+
+template <typename T>
 hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, int tile, hipStream_t stream,
                             const char *&name) {
-    if (p.out_in_place && tile > 14) tile = 0; /* only the strip kernels know in-place addressing */
+    if (p.out_in_place && tile > 16) tile = 0; /* only the strip kernels know in-place addressing */
     switch (tile) {
     case 6401:
         name = FR_KNAME("escape_kernel", "64x1");
@@ -3203,8 +3227,7 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
             /* Julia views are mostly short orbits with a heavy tail: two passes (see escape_first_kernel; the
              * host asks for it from 65 536 tiles up: fr_wants_two_pass) */
-            name = p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
-                                : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            name = first_pass_name<T>(p);
             return launch_two_pass<T>(p, out, stream);
         }
         if (tiles >= 262144) {
@@ -3214,14 +3237,18 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
                 name = FR_KNAME("escape_refill_kernel", "7x2-tile patches");
                 return launch_refill<T, 7>(p, mode, out, stream);
             }
+        }
+        /* p.strip_tiles: the length the view's own statistics call for (fr_api.hip: choose_kernel); else by launch size */
+        const uint32_t k_len = (mode == FR_OUT_RGB && p.strip_tiles) ? p.strip_tiles : tiles >= 262144 ? 7u : tiles >= 65536 ? 4u : tiles >= 16384 ? 2u : 1u;
+        if (k_len >= 7u) {
             name = FR_KNAME("escape_strip_kernel", "7 tiles");
             return launch_strips<T, 7>(p, mode, out, stream);
         }
-        if (tiles >= 65536) {
+        if (k_len >= 4u) {
             name = FR_KNAME("escape_strip_kernel", "4 tiles");
             return launch_strips<T, 4>(p, mode, out, stream);
         }
-        if (tiles >= 16384) {
+        if (k_len >= 2u) {
             name = FR_KNAME("escape_strip_kernel", "2 tiles");
             return launch_strips<T, 2>(p, mode, out, stream);
         }
@@ -3232,22 +3259,23 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
         name = FR_KNAME("escape_strip_kernel", "7 tiles");
         return launch_strips<T, 7>(p, mode, out, stream);
     case 13: /* the first pass alone: no tile is handed over, no lists, no second kernel */
+    case 16: /* ... in 4-tile strips */
     case 12: /* two passes with round 2's first pass (comparison only) */
         if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
             if (tile == 12) {
                 name = FR_KNAME("escape_first_v1_kernel + escape_queue_kernel", "round 2's first pass, then persistent waves over the survivor lists");
                 return launch_two_pass<T>(p, out, stream, true);
             }
-            name = p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
-                                : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
+            name = first_pass_name<T>(p);
             return launch_two_pass<T>(p, out, stream);
         }
         [[fallthrough]];
     case 14: /* two passes with round 2's second-pass kernel (comparison only) */
+    case 15: /* two passes, the first in 4-tile strips */
     case 11: /* two passes: strips to first_cap, then persistent waves over the survivors (otherwise as 9) */
         if (mode == FR_OUT_RGB && p.first_cap != 0 && (p.first_only || (p.surv_counts && p.work_counter))) {
             name = tile == 14 ? FR_KNAME("escape_first_kernel + escape_queue_kernel", "7-tile strips, then round 2's persistent waves over the survivor lists")
-                              : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
+                              : first_pass_name<T>(p);
             return launch_two_pass<T>(p, out, stream);
         }
         if (p.algo != 0 && p.algo != 2) {
@@ -3309,7 +3337,8 @@ __global__ __launch_bounds__(256) void recursive_batch_kernel(uint32_t iteration
  * totals to `result` (host-mapped) and zeroes the counters for the next sample.  Colours nothing, stores nothing. */
 template <typename T>
 __global__ __launch_bounds__(64) void view_sample_kernel(const fr_kparams p, uint32_t side, uint32_t cap_s, uint32_t episode, uint32_t keep,
-                                                         unsigned long long *counters, unsigned long long *result) {
+                                                         unsigned long long *counters, unsigned long long *result,
+                                                         unsigned long long tag) {
     const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
     const uint32_t ti = blockIdx.x % side, tj = blockIdx.x / side;
     /* tile origin: the centre of cell (ti, tj) of the grid, aligned down to a multiple of 8 */
@@ -3371,6 +3400,9 @@ __global__ __launch_bounds__(64) void view_sample_kernel(const fr_kparams p, uin
             }
             atomicExch(counters + 7, 0ull);
             __threadfence_system();
+            /* the tag LAST: a host that polls result[7] for it (the non-blocking sample of GUI-sized frames) reads
+             * complete totals once it sees it */
+            __hip_atomic_store(result + 7, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -3493,7 +3525,8 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint) {
          * f64, against the strips the default would otherwise pick): 65 536 tiles 0.17 / 0.21 ms against 0.18 / 0.30,
          * 131 072 tiles 0.17 / 0.22 against 0.20 / 0.33; at 32 768 tiles and below the strips win in f32 */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
-        if (tiles < 65536) return false;
+        if (tiles < 65536 && hint < 1) return false; /* (a MEASURED view may ask for them from 4096 tiles up) */
+        if (tiles < 4096) return false;
         /* which of the two suits the IMAGE is measured where that pays (hint: 1 two passes, 0 strips — fr_api.hip:
          * choose_kernel); without a measurement, by the algorithm: Julia views are mostly short orbits with a heavy tail */
         if (hint == 0 || (hint < 0 && p.algo != 2)) return false;
@@ -3501,11 +3534,12 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint) {
          * 2048^2: 0.055 ms in two passes, 0.039 in strips; profiles/r03_kernel_choice_views.txt, mid-size section) */
         if (hint < 0 && p.iterations < 512u) return false;
         p.first_only = hint == 2 ? 1u : 0u;
-    } else if (tile == 13) {
+    } else if (tile == 13 || tile == 16) {
         p.first_only = 1u;
-    } else if (tile != 11 && tile != 12 && tile != 14) {
+    } else if (tile != 11 && tile != 12 && tile != 14 && tile != 15) {
         return false;
     }
+    if (tile == 15 || tile == 16) p.strip_tiles = 4u;
     /* first_cap: a multiple of the loop's block length; the second pass must have something left to do */
     uint32_t k1 = p.two_pass_cap ? p.two_pass_cap : 64u; /* measured on C4: 64 / 48 (tools/sweep_two_pass.py) */
     k1 = (k1 + 3u) & ~3u;
@@ -3579,12 +3613,13 @@ hipError_t fr_launch_colour(const fr_kparams &p, const double *z, const uint32_t
 }
 
 hipError_t fr_launch_view_sample(const fr_kparams &p, int precision, uint32_t side, uint32_t cap_s, uint32_t episode, uint32_t keep,
-                                 unsigned long long *counters, unsigned long long *result, hipStream_t stream) {
+                                 unsigned long long *counters, unsigned long long *result, unsigned long long tag,
+                                 hipStream_t stream) {
     if (side == 0 || p.ncols == 0 || p.nrows == 0) return hipErrorInvalidValue;
     if (precision == 1)
-        hipLaunchKernelGGL(view_sample_kernel<float>, dim3(side * side), dim3(64), 0, stream, p, side, cap_s, episode, keep, counters, result);
+        hipLaunchKernelGGL(view_sample_kernel<float>, dim3(side * side), dim3(64), 0, stream, p, side, cap_s, episode, keep, counters, result, tag);
     else
-        hipLaunchKernelGGL(view_sample_kernel<double>, dim3(side * side), dim3(64), 0, stream, p, side, cap_s, episode, keep, counters, result);
+        hipLaunchKernelGGL(view_sample_kernel<double>, dim3(side * side), dim3(64), 0, stream, p, side, cap_s, episode, keep, counters, result, tag);
     return hipGetLastError();
 }
 

@@ -105,29 +105,25 @@ struct Rccl {
         if (r == 0) return FR_OK;
         return fail(FR_ERR_HIP, std::string(what) + ": " + GetErrorString(r));
     }
-    void destroy_comms() {
-        std::lock_guard<std::mutex> lk(comm_mu);
-        for (ncclComm_t c : comms)
-            if (c) (void)CommDestroy(c);
-        comms.clear();
-        aborted = false;
+    /* Ownership rule: communicator r is used, aborted and destroyed ONLY by logical device r's worker
+     * thread — nobody ever pulls a handle from under a thread that may be inside an RCCL call on it.  A rank that
+     * fails, or that sees the set's abort flag while it waits for its transfers, aborts ITS OWN communicator
+     * (ncclCommAbort releases the operations in flight on it: its peers' matching device-side waits then fail or
+     * finish, and each of them aborts its own in turn).  After a failed render run_multi() has every worker drop
+     * what is left (abort, not destroy: a communicator whose peers were aborted may not be destroyed collectively)
+     * and the next RCCL render makes new ones. */
+    void abort_own(uint32_t r) {
+        if (r >= comms.size() || !comms[r]) return;
+        if (CommAbort) (void)CommAbort(comms[r]);
+        comms[r] = nullptr; /* (without ncclCommAbort in the library: leaked rather than hung on) */
+        aborted.store(true, std::memory_order_release);
     }
-    /* A rank failed in the middle of a gather: its peers are (or will be) waiting in device-side receives /
-     * sends that it will never match.  ncclCommAbort is the call RCCL provides for exactly this — it may be
-     * made from any thread and releases the operations in flight on that communicator.  Every communicator
-     * of the set is aborted once; run_multi() drops them afterwards and the next RCCL render makes new ones. */
-    void abort_all() {
-        std::lock_guard<std::mutex> lk(comm_mu);
-        if (aborted) return;
-        aborted = true;
-        for (ncclComm_t &c : comms) {
-            if (!c) continue;
-            if (CommAbort) (void)CommAbort(c);
-            c = nullptr; /* aborted communicators are gone (without ncclCommAbort: leaked rather than hung on) */
-        }
+    void destroy_own(uint32_t r) {
+        if (r >= comms.size() || !comms[r]) return;
+        (void)CommDestroy(comms[r]);
+        comms[r] = nullptr;
     }
-    std::mutex comm_mu;
-    bool aborted = false;
+    std::atomic<bool> aborted{false};
 };
 
 /* ---- one worker thread per logical device ----------------------------------------------------- */
@@ -476,10 +472,28 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     }
 #undef HIP_BRK
     if (rc != FR_OK) {
-        /* tell the others, and — RCCL — release the peers that wait for transfers this device will never post */
+        /* tell the others, and — RCCL — release the peers that wait for transfers this device will never post: this
+         * rank's own communicator only, from this thread, its owner (see Rccl::abort_own) */
         j.abort->store(true, std::memory_order_release);
         if (j.pins) j.pins->wake();
-        if (j.sink == Sink::Rccl) rc_lib.abort_all();
+        if (j.sink == Sink::Rccl) rc_lib.abort_own(r);
+    } else if (j.sink == Sink::Rccl && n > 1) {
+        /* A healthy rank waits for its transfers by POLLING, so that it can see the abort flag: a peer that failed will
+         * never post the matching operation, and a device-side wait on it would block hipStreamSynchronize for ever.
+         * Seeing the flag, it aborts its own communicator — which ends its operations in flight — and reports an echo. */
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx.copy_stream);
+            if (q != hipErrorNotReady) {
+                if (q != hipSuccess) (void)hipGetLastError();
+                break;
+            }
+            if (j.abort->load(std::memory_order_acquire)) {
+                rc_lib.abort_own(r);
+                rc = fail(FR_ERR_HIP, kEchoError);
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     }
     /* drain, error or not */
     hipError_t e1 = hipStreamSynchronize(ctx.stream);
@@ -501,6 +515,24 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     stats->kernel_ms[r] = total;
     stats->rows[r] = my_rows;
     return FR_OK;
+}
+
+/* Every worker drops its own communicator on its own thread (abort after a failed gather, destroy at shutdown). */
+void drop_comms(DeviceSet &set, bool abort) {
+    Rccl *lib = &set.rccl;
+    if (lib->comms.empty()) return;
+    for (auto &w : set.workers) {
+        Worker *wp = w.get();
+        wp->post([wp, lib, abort] {
+            (void)hipSetDevice(wp->ctx.hip_device);
+            if (abort) lib->abort_own((uint32_t)wp->index);
+            else lib->destroy_own((uint32_t)wp->index);
+            return (int)FR_OK;
+        });
+    }
+    for (auto &w : set.workers) (void)w->wait();
+    lib->comms.clear();
+    lib->aborted.store(false, std::memory_order_release);
 }
 
 int ensure_rccl(DeviceSet &set) {
@@ -544,7 +576,7 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
     Job job{cfg, precision, default_opts(), block_rows, (uint32_t)(((uint64_t)cfg->height + block_rows - 1) / block_rows), n, sink,
             dst, dst_len, set->devices[0], pins.get(), set, &abort};
     /* which kernel suits the view: decided once for the whole image (on the first device), not by every chunk launch */
-    if (hipSetDevice(set->devices[0]) == hipSuccess) decide_kernel(set->workers[0]->ctx, cfg, precision, 0, cfg->height, job.opts);
+    if (hipSetDevice(set->devices[0]) == hipSuccess) decide_kernel(set->workers[0]->ctx, cfg, precision, 0, cfg->height, job.opts, nullptr, false);
     (void)hipGetLastError();
     fr_multi_stats stats;
     memset(&stats, 0, sizeof stats);
@@ -567,7 +599,7 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
         }
     }
     if (pins) pins->finish(); /* every device has drained its streams */
-    if (sink == Sink::Rccl && abort.load()) set->rccl.destroy_comms(); /* aborted: the next RCCL render makes new ones */
+    if (sink == Sink::Rccl && (abort.load() || set->rccl.aborted.load())) drop_comms(*set, true); /* the next RCCL render makes new ones */
     stats.wall_ms = now_ms() - t_start;
     tl_stats = stats;
     if (rc != FR_OK) return fail(rc, first_err);
@@ -581,7 +613,7 @@ void multi_shutdown_locked() {
     DeviceSet *set = g_set;
     g_set = nullptr;
     if (!set) return;
-    set->rccl.destroy_comms();
+    drop_comms(*set, false);
     for (auto &w : set->workers) {
         {
             std::lock_guard<std::mutex> lk(w->m);

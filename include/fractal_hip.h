@@ -313,10 +313,10 @@ int fr_last_kernel_ms(float *ms);
 int fr_last_kernel_name(char *buf, size_t buf_len);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
- * 0 = default: strips of 8x8 tiles (strip length by image size) for launches under 65 536 tiles; from there up two passes
- *     (11) for Julia images and strips otherwise; from 131 072 tiles up whichever of strips / 13 / 11 a sample of the
- *     image calls for (fr_set_dispatch_sampling);
- * 1, 2, 4 = that kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
+ * 0 = default: strips of 8x8 tiles (strip length 1 / 2 / 4 / 7 tiles by launch size) unless the view's own statistics call for
+ *     another kernel — see fr_set_dispatch_sampling; without statistics (the first frame of a GUI-sized view, sampling
+ *     off): two passes (11) for Julia images of 65 536 tiles and more with a cap of 512 and more, strips otherwise;
+ * 1, 2, 4 = the strip kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
  * 9 = 7-tile strips with lane refill;
  * 10 = the work-queue kernel (persistent waves drawing 64x32-pixel patches from a device-wide counter, unchecked
  *      blocks of iterations, results finished and coloured 64 at a time; RGB renders of an escape-time algorithm
@@ -328,27 +328,44 @@ int fr_last_kernel_name(char *buf, size_t buf_len);
  *      lists live in a context-owned ring of three buffers cut from one allocation: per entry 20 bytes (f32 Julia),
  *      28 (f64 Julia; f32 Mandelbrot), 44 (f64 Mandelbrot), one entry per eight pixels of the launch (at most 2^28
  *      entries) — C4 in f32: 671 MB per buffer, 2 GB for the ring.  The ring exists from the context's creation on
- *      for frames up to 3840 x 2160 (3 x 48 MiB) and is re-allocated only for a launch that needs more: the one allocation
- *      a device-pointer render can block on (~15 ms, once per size never seen before).  A list that is full costs speed only;
+ *      for frames up to 3840 x 2160 (3 x 48 MiB, best effort) and is re-allocated only for a launch that needs more: the one
+ *      allocation a device-pointer render can block on (~15 ms, once per size never seen before; other threads' renders that
+ *      need no lists are not held up by it).  A list that is full costs speed only;
  * 12 = two passes with round 2's two kernels (kept for comparisons: tools/c4_ab.py);
  * 13 = the first pass of 11 alone: no tile is handed over (every lane finishes in place), no lists, no second kernel;
  * 14 = 11 with round 2's second-pass kernel behind this round's first pass (kept for comparisons);
+ * 15 = 11 with the first pass in 4-tile strips, 16 = 13 in 4-tile strips (GUI-sized launches: four times as many
+ *      workgroups to balance over the chip);
  * 6401, 3202, 1604, 808 = the 4-wave-workgroup kernel with a 64x1 / 32x2 / 16x4 / 8x8 per-wave
  * pixel footprint. */
 int fr_set_tile(int tile);
 
-/* The default dispatch (tile 0) chooses between strips and two passes from the IMAGE: for launches of 131 072
- * tiles (4096 x 2048 pixels) and more it renders a sample of 256 tiles through the plain loop (~20 us of device time
- * on a stream of the library's own, ~40 us of the caller's) and takes two passes when one-tile-per-wave rendering would
- * keep less than 0.8 of its lanes busy.  The last 32 (view, launch) pairs are remembered.  This is the ONE step of
- * the device-pointer entry points that blocks the calling thread; 0 switches it off (then: two passes for Julia
- * images from 2048^2 up, strips otherwise, as for smaller launches).  Same bytes either way. */
+/* The default dispatch (tile 0) chooses its kernel from the IMAGE: a sample of 16 x 16 tiles of the launch goes through the
+ * plain loop (capped at 4096 iterations; ~20-70 us of device time) and reports the share of pixels still running at the cap
+ * (`capped`), the share the two-pass render would hand over to its lists (`handed`), the lane-iterations that finishing those
+ * in place would idle away as a share of the work (`waste`) and the mean iteration count.
+ *   Launches of 131 072 tiles (4096 x 2048 pixels) and more — the sample is taken in FRONT of the first launch of a view,
+ *   on a stream of the library's own, and the calling thread waits for it (~40 us): the ONE step of the device-pointer entry
+ *   points that blocks.  Rule: capped >= 0.10 and waste < 0.01 -> strips; else handed >= 0.002 (or >= 4096 handed-over
+ *   pixels with >= 128 iterations to go on average) -> two passes; else the first pass alone.
+ *   Launches of 4096 .. 131 072 tiles — every frame the reference's GUI asks for (src/gui.rs:56-82) — NEVER block: the first
+ *   frame of a view is dispatched by algorithm and size as described under fr_set_tile, the sample is enqueued BEHIND its
+ *   render, and the next frame of the same view is dispatched from the measured numbers (rule: DESIGN.md 3.2d).
+ * A view is identified by the fields that determine orbits (algo, width, height, iterations, limit, pos, scale, julia_set),
+ * the launch's rows and the precision: changing colours, exposure, smooth or inside keeps it.  The last 32 views are
+ * remembered.  No sample is taken while `hip_stream` is being captured into a graph.  0 switches sampling off (dispatch
+ * by algorithm and size only).  Same bytes either way. */
 int fr_set_dispatch_sampling(int enabled);
-/* Tool / test hook: the sample of the whole image. out[0..5] = executed iterations, 64 x the sum of the tiles' longest
- * orbits, tiles, lanes at the sample's cap of 1024, lanes the two-pass render would hand over after its first episode,
- * lane-iterations that finishing those in place would waste; out[6] = out[0] / out[1], the useful-lane fraction of
- * one-tile-per-wave rendering; out[7] = iterations the handed-over lanes would still have to run. */
+/* Tool / test hook: the (blocking) sample of the whole image. out[0..5] = executed iterations, 64 x the sum of the tiles'
+ * longest orbits, tiles, lanes at the sample's cap (min(iterations, 4096)), lanes the two-pass render's first-pass schedule
+ * would hand over, lane-iterations that finishing those in place would waste; out[6] = out[0] / out[1], the useful-lane
+ * fraction of one-tile-per-wave rendering; out[7] = iterations the handed-over lanes would still have to run. */
 int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]);
+/* Tool / test hook: what the default dispatch has on record for the view (cfg, rows [y0, y1), precision) as ONE launch:
+ * *state = 0 nothing, 1 a non-blocking sample is in flight, 3 its totals have arrived (the next frame reads them), 2 decided; *choice = -1 none, 0 strips, 1 two passes, 2 the first
+ * pass alone; *strip_tiles = the strip length it asks for (0 = by launch size).  Touches nothing. */
+int fr_debug_view_choice(const fr_config *cfg, int precision, uint32_t y0, uint32_t y1, int *state, int *choice,
+                         uint32_t *strip_tiles);
 
 /* Policy of the lane-refilling kernels (tuning studies): an orbit episode may end early, so that
  * idle lanes get new pixels, once quit16/16 of its running lanes (work-queue kernel: of the wave's 64 lanes)

@@ -253,6 +253,26 @@ int fro_escape_rows(const fro_config *cfg, int precision, uint32_t y0, uint32_t 
     return nt;
 }
 
+/* get_recursive_pixel's colour map alone — calc/src/lib.rs:214-234 — over n stored recursive() results
+ * (z[2k], z[2k+1] = final position, iters[k] = escape index): what the rest of get_recursive_pixel does
+ * with `recursive`'s return value (:212).  Lets a caller colour one escape pass with both log2 modes. */
+int fro_colour_rows(const fro_config *cfg, const double *z, const uint32_t *iters, size_t n, uint8_t *out,
+                    int threads) {
+    int nt = pick_threads(threads);
+    const int escape_algo = cfg->algo == FRO_ALGO_MANDELBROT || cfg->algo == FRO_ALGO_JULIA;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t k = 0; k < (int64_t)n; k++) {
+        fro_imaginary pos;
+        pos.re = z[2 * k];
+        pos.im = z[2 * k + 1];
+        fro_rgb p = escape_algo ? colour_of(cfg, pos, iters[k]) : fro_rgb_new(0, 0, 0); /* :211 */
+        out[3 * k + 0] = p.r;
+        out[3 * k + 1] = p.g;
+        out[3 * k + 2] = p.b;
+    }
+    return nt;
+}
+
 static uint64_t executed_of(const fro_config *cfg, uint32_t iters) {
     /* escape at 0-based index i ran i+1 loop bodies; exhaustion ran `iterations` */
     return iters < cfg->iterations ? (uint64_t)iters + 1u : (uint64_t)cfg->iterations;

@@ -105,6 +105,12 @@ int fro_get_image_rows(const fro_config *cfg, int precision, uint32_t y0, uint32
 int fro_escape_rows(const fro_config *cfg, int precision, uint32_t y0, uint32_t y1, double *z,
                     uint32_t *iters, int threads);
 
+/* The colour map of get_recursive_pixel alone (calc/src/lib.rs:214-234 + color_multiply) over n stored
+ * recursive() results, e.g. the arrays fro_escape_rows produced; out holds 3*n bytes r,g,b.  Uses the log2
+ * mode currently selected. */
+int fro_colour_rows(const fro_config *cfg, const double *z, const uint32_t *iters, size_t n, uint8_t *out,
+                    int threads);
+
 /* Strided sample of the image (every sx-th column, sy-th row, same per-pixel function):
  * returns Σ executed iterations over the sampled pixels (i+1 on escape at
  * index i, `iterations` on exhaustion) and, if out != NULL, their colours. */

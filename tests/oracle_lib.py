@@ -84,6 +84,8 @@ def lib():
     L.fro_get_image_rows.argtypes = [C.POINTER(Config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
     L.fro_escape_rows.restype = C.c_int
     L.fro_escape_rows.argtypes = [C.POINTER(Config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    L.fro_colour_rows.restype = C.c_int
+    L.fro_colour_rows.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     L.fro_sample_image.restype = C.c_uint64
     L.fro_sample_image.argtypes = [C.POINTER(Config), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_uint64)]
@@ -157,6 +159,15 @@ def escape_rows(cfg, precision=F64, y0=0, y1=None, threads=0):
     it = np.empty((y1 - y0, cfg.width), dtype=np.uint32)
     lib().fro_escape_rows(C.byref(cfg), precision, y0, y1, z.ctypes.data, it.ctypes.data, threads)
     return z, it
+
+
+def colour_rows(cfg, z, it, threads=0):
+    """The colour map alone (calc/src/lib.rs:214-234) over stored recursive() results -> uint8 [..., 3]."""
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    it = np.ascontiguousarray(it, dtype=np.uint32)
+    out = np.empty(it.shape + (3,), dtype=np.uint8)
+    lib().fro_colour_rows(C.byref(cfg), z.ctypes.data, it.ctypes.data, it.size, out.ctypes.data, threads)
+    return out
 
 
 def sample_image(cfg, sx, sy, precision=F64, threads=0, colours=True):

@@ -357,6 +357,33 @@ def test_multi_device_failure_drains_and_recovers(fr, lib, sink):
     fr.init_devices([0])
 
 
+def test_multi_device_failure_rccl_sink_needs_two_gpus(fr, lib):
+    """the same injected failure with sink = RCCL.  Each rank aborts only ITS OWN communicator, from its owner
+    thread (fr_multi.hip: Rccl::abort_own); healthy ranks wait for their transfers by polling and see the abort flag.  A
+    communicator cannot hold one GPU twice, so this needs two distinct devices: SKIPPED on the one-GPU box of this
+    pipeline — it is here for the first multi-GPU box that runs the suite."""
+    import torch
+
+    if fr.device_count() < 2:
+        pytest.skip("needs two distinct GPUs (an RCCL communicator cannot hold one GPU twice)")
+    from fractal_renderer_amd import _native
+
+    fr.init_devices([0, 1])
+    cfg, _ = cfg_of(fr, 1536, 4096, 180)
+    want = fr.get_image(cfg)
+    d = torch.zeros(want.nbytes, dtype=torch.uint8, device="cuda:0")
+    for dev, chunk in ((1, 0), (0, 1), (1, 2)):
+        _native.check(lib.fr_debug_inject_multi_failure(dev, chunk))
+        rc = lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 64, 1, C.c_void_p(d.data_ptr()), d.numel())
+        assert rc == 4, (dev, chunk, rc)
+        assert "injected failure" in lib.fr_last_error().decode()
+        _native.check(lib.fr_debug_inject_multi_failure(-1, 0))
+        d.zero_()
+        _native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 64, 1, C.c_void_p(d.data_ptr()), d.numel()))
+        assert np.array_equal(d.cpu().numpy().reshape(want.shape), want), (dev, chunk)
+    fr.init_devices([0])
+
+
 def test_multi_host_buffer_pinned_by_the_caller(fr, lib):
     """fr_pin_host_buffer: a frame buffer that is rendered into again and again is pinned once by its owner; the
     multi-device and the single-device host renders find it registered and produce the same bytes."""
