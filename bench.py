@@ -140,10 +140,38 @@ def cpu_baseline(cfg_bytes, precision, threads, sample):
     return {"value": total / dt, "seconds": dt, "pixels": npx, "pixel_iterations": total, "threads": threads}, colours, total
 
 
+def loop_mix(kernel_name):
+    """Vector instructions the kernel's orbit loop issues per iteration (counted in the ISA:
+    profiles/r01_inner_loop_isa.txt, profiles/r03_c4_first_pass_classes.txt) and what that mix can reach of the nominal
+    vector peak if every one of them issued at the arithmetic type's rate and every lane was busy:
+    10 flops (the reference's count) / (instructions x 1 lane-slot each) / 2 flops per FMA slot."""
+    if "first_kernel" in kernel_name or "second_kernel" in kernel_name or "queue_kernel" in kernel_name:
+        n, what = 6.75, ("scaled form in unchecked blocks of 4 iterations with a per-lane count: 24 arithmetic + |z|^2 <= T test + "
+                         "count + freeze per block = 27 / 4")
+    elif "strip_kernel" in kernel_name or "refill_kernel" in kernel_name:
+        n, what = 6.5, ("scaled form X = 2re, Y = 2im, A = X^2, B = Y^2: 6 per iteration + one distance add and one compare per "
+                        "block of 4 = 26 / 4 (the reference as written: 8 arithmetic + 1 compare = 9)")
+    else:
+        n, what = 9.0, "the reference's iteration as written: 8 arithmetic + 1 compare"
+    return n, what
+
+
 def roofline_block(prec_name, launch_px_it, kernel_ms, pixels, kernel_name, traffic):
     peak = FP32_VECTOR_PEAK_TFLOPS if prec_name == "f32" else FP64_VECTOR_PEAK_TFLOPS
     achieved = FLOPS_PER_ITERATION * launch_px_it / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    n_instr, mix_what = loop_mix(kernel_name)
+    mix_ceiling = FLOPS_PER_ITERATION / (2.0 * n_instr)
+    rate = launch_px_it / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
     return {
+        "loop_vector_instructions_per_iteration": n_instr,
+        "loop_mix": mix_what,
+        "mix_ceiling_frac": mix_ceiling,
+        "frac_of_mix_ceiling": achieved / peak / mix_ceiling,
+        "fraction_of_attainable": 8.0 * rate / (peak / 2.0 * 1e12),
+        "fraction_of_attainable_note": "BASELINE.md §2's second figure, 8 x rate / (peak / 2): it prices the loop at 8 non-fused "
+                                       "vector operations per iteration; this kernel issues %.2f (%s), which is why the figure can "
+                                       "exceed 1 — no iteration is skipped: the executed-iteration sum and every output byte equal the "
+                                       "CPU oracle's (cpu_baseline.gpu_*_identical_on_sample)" % (n_instr, mix_what.split(":")[0]),
         "bound": "valu_f64" if prec_name == "f64" else "valu_f32",
         "achieved": achieved,
         "peak": peak,
@@ -185,6 +213,14 @@ def roofline_with_pmc(block, rec):
         rec.get("date", "?"), rec["build_id"])
     block["valu_issue_util"] = rec.get("valu_issue_util")
     block["valu_issue_util_note"] = rec.get("valu_issue_util_note")
+    if rec.get("active_cycles") and rec.get("kernel_ms_under_profiler"):
+        # the clock the render kernels actually ran at in the profiled run: active cycles / their duration (nominal 2.4 GHz)
+        block["measured_clock_ghz"] = rec["active_cycles"] / (rec["kernel_ms_under_profiler"] * 1e-3) / 1e9
+        block["measured_clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs / the kernels' duration in the same profiled run (%s); peak is quoted at 2.4 GHz" % rec.get("source", "?")
+    if rec.get("sq_insts_valu"):
+        block["vector_instructions_per_launch"] = rec["sq_insts_valu"]
+        block["loop_floor_vector_instructions_per_launch"] = block["algorithmic_flops_per_launch"] / FLOPS_PER_ITERATION / 64.0 * block[
+            "loop_vector_instructions_per_iteration"]
     return block
 
 
@@ -515,6 +551,30 @@ def run_single(args, torch, fr, lib, native):
         if threads > 16:
             i16, _, _ = cpu_baseline(bytes(cfg), int(prec), 16, max(sample, 2))
             base["value_16_threads"] = i16["value"]
+        if is_c2:
+            # BASELINE C1 — the README's frame (README.md:9-11, examples.md:29: 3000x3000 -s 1e6 -i 1024), "the repo's existing
+            # rayon CPU path": the CPU leg in full ("C1 and C2 timed in full") beside the drop-in call for it
+            import numpy as np
+
+            c1 = make_config(fr, "zoom1e6", 3000, 1024)
+            i1, colours1, total1 = cpu_baseline(bytes(c1), int(fr.Precision.F64), threads, 1)
+            buf1 = np.empty((3000, 3000, 3), dtype=np.uint8)
+            fr.get_image_rows(c1, 0, 3000, fr.Precision.F64, out=buf1)
+            calls = []
+            for _ in range(10):
+                tc = time.perf_counter()
+                fr.get_image_rows(c1, 0, 3000, fr.Precision.F64, out=buf1)
+                calls.append((time.perf_counter() - tc) * 1e3)
+            m1 = sg.measure(c1, fr.Precision.F64, 10, 2)
+            base["C1_frame"] = {
+                "workload": "mandelbrot 3000x3000 max_iter=1024 f64 view=zoom1e6 (BASELINE C1, the README's frame), whole frame",
+                "cpu_seconds": i1["seconds"], "cpu_value": i1["value"], "cpu_threads": threads, "pixel_iterations": total1,
+                "gpu_kernel_ms": m1["kernel_ms"], "gpu_kernel": m1["kernel"], "gpu_value_kernel_only": total1 / (m1["kernel_ms"] * 1e-3),
+                "gpu_host_call_ms_median": sorted(calls)[5],
+                "gpu_iteration_sum_identical": bool(m1["total"] == total1),
+                "gpu_bytes_identical": bool((buf1 == colours1).all()),
+                "note": "get_image for the README's frame: the oracle's row-parallel driver on the host cores against "
+                        "fr_render_rows_rgb8 into a host buffer (kernel + D2H); the reference quotes '~1 second' for it on a laptop (README.md:11)"}
         out["cpu_baseline"] = base
         out["gpu_over_cpu"] = rate / info["value"]
     print(json.dumps(out), flush=True)

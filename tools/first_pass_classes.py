@@ -109,7 +109,10 @@ def regions(listing):
 
 
 def main():
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S"]
+    # the flags the library is BUILT with (fractal-renderer_amd/build.py via the lint's helper): the ISA classed is the ISA that ships
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scan_asm_hazards
+    flags = scan_asm_hazards.build_flags()[0] + ["--cuda-device-only", "-S"]
     with tempfile.TemporaryDirectory() as td:
         s = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-o", s, os.path.join(CSRC, "fr_kernels.hip")], check=True, cwd=CSRC,
