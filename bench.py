@@ -50,6 +50,9 @@ VIEWS = {
     "default": ("mandelbrot", (-0.6, 0.0), 0.4, None),
     "zoom1e6": ("mandelbrot", (-0.7436447860, 0.1318252536), 1e6, None),
     "julia": ("julia", (0.0, 0.0), 0.4, (-0.8, 0.156)),
+    # gui_latency only: a filled Julia set (the basilica) and a thin dust of a dozen iterations per pixel
+    "filled_julia": ("julia", (0.0, 0.0), 0.4, (-1.0, 1e-9)),
+    "thin_dust": ("julia", (0.0, 0.0), 0.4, (0.4, 0.4)),
 }
 
 
@@ -305,7 +308,7 @@ def whole_image_cpu_compare(sg, line):
                  "cpu_seconds": info["seconds"], "cpu_threads": info["threads"]})
 
 
-def gui_latency(fr):
+def gui_latency(fr, lib, native):
     """SURVEY.md §8 f2, driver-timed: what a GUI-shaped caller sees — the reference's render thread
     calls get_image for every redraw (src/gui.rs:56-82) and hands RGBA to egui (:71-72); `S` starts a 2x screenshot
     on another thread while redraws go on (:322-326).  Per frame shape: the FIRST call of the process for that shape,
@@ -318,9 +321,18 @@ def gui_latency(fr):
     frames = [("750x500 i=50 (CLI defaults, src/lib.rs:34-50)", 750, 500, 50), ("1500x1000 i=50 (the 2x screenshot of it)", 1500, 1000, 50),
               ("1920x1080 i=1024", 1920, 1080, 1024), ("3840x2160 i=1024", 3840, 2160, 1024)]
     out = {}
-    for view in ("default", "julia"):
+    native.check(lib.fr_set_profiling(1))  # fr_last_kernel_name: which kernel a frame's render launched
+    kname = C.create_string_buffer(256)
+
+    def last_kernel():
+        native.check(lib.fr_last_kernel_name(kname, len(kname)))
+        return kname.value.decode()
+
+    for view in ("default", "julia", "filled_julia", "thin_dust"):
         rows = {}
-        for label, w, h, it in frames:
+        for label, w, h, it in (frames if view in ("default", "julia") else frames[2:]):
+            if view == "thin_dust":
+                it, label = 256, label.replace("i=1024", "i=256")
             cfg = make_config(fr, view, 16, it)
             cfg.width, cfg.height = w, h
             rec = {}
@@ -331,14 +343,22 @@ def gui_latency(fr):
                 t0 = time.perf_counter()
                 call(buf)
                 first = (time.perf_counter() - t0) * 1e3
+                k_first = last_kernel()
                 ts = []
                 for _ in range(50):
                     t0 = time.perf_counter()
                     call(buf)
                     ts.append((time.perf_counter() - t0) * 1e3)
+                second = ts[0]
                 ts.sort()
-                rec[fmt] = {"first_call_ms": first, "median_ms": ts[25], "p95_ms": ts[47]}
+                # kernel_first_frame: dispatched by size (nothing is known about the view yet; its sample runs behind the render);
+                # kernel_steady: dispatched from the view's own statistics, from the second frame on
+                rec[fmt] = {"first_call_ms": first, "second_call_ms": second, "median_ms": ts[25], "p95_ms": ts[47],
+                            "kernel_first_frame": k_first, "kernel_steady": last_kernel()}
             rows[label] = rec
+        if view not in ("default", "julia"):
+            out["julia -1 (filled: the basilica)" if view == "filled_julia" else "julia 0.4+0.4i (a thin dust, ~10 iterations a pixel)"] = rows
+            continue
         # render thread + screenshot thread (2x) at once: 30 redraws of 750x500 while 3 screenshots of 1500x1000 render
         small = make_config(fr, view, 16, 50)
         small.width, small.height = 750, 500
@@ -367,6 +387,7 @@ def gui_latency(fr):
         rows["render thread (750x500) beside the screenshot thread (1500x1000), two host threads"] = {
             "redraw_median_ms": redraw[len(redraw) // 2], "redraw_max_ms": redraw[-1], "screenshot_median_ms": sorted(shots)[1]}
         out["mandelbrot default view" if view == "default" else "julia -0.8+0.156i (C4's view)"] = rows
+    native.check(lib.fr_set_profiling(0))
     out["note"] = ("fr_render_rows_rgb8 / fr_render_rows_rgba8 into a resident host buffer, f64, wall time of the call (kernel + D2H "
                    "+ call overhead); first_call_ms = the first call of this process for that frame shape")
     return out
@@ -495,7 +516,7 @@ def run_single(args, torch, fr, lib, native):
 
     # the other single-GPU BASELINE configs, driver-timed in the same run (C3 is ~1.2 s a step: 2 steps)
     if is_c2:
-        out["gui_latency"] = gui_latency(fr)
+        out["gui_latency"] = gui_latency(fr, lib, native)
         out["other_configs"]["C3"] = other_config_line(sg, fr, "C3", "zoom1e6", 65536, "f64", 2, 1)
         out["other_configs"]["C3"].pop("_compare", None)
         # C5's image (65536^2, 12.9 GB) on ONE device: what each of 8 GPUs would share out; the 8-GPU run is the driver's

@@ -618,7 +618,8 @@ std::atomic<int> g_dispatch_sampling{1};
  * the precision): a GUI changing colours, exposure, smooth or inside (src/gui.rs:183-203) keeps its view.  The last 32
  * views are remembered.  No sample while the caller's stream is being captured into a graph (neither a host wait nor a
  * cross-stream event belongs in a capture).  Returns 1 two passes, 2 first pass alone, 0 strips, -1 no opinion. */
-constexpr uint64_t kSampleMinTiles = 131072;
+constexpr uint64_t kSampleMinTiles = 131072; /* from here up the sample is taken in front of the first launch (blocking) */
+constexpr uint64_t kMidRuleTiles = 524288;   /* under 8192 x 4096: the rule fitted to GUI-sized launches */
 constexpr uint64_t kAsyncMinTiles = 4096;
 constexpr uint32_t kSampleCap = 4096;
 
@@ -658,11 +659,11 @@ struct Decision {
     uint32_t strip_tiles;
 };
 
-static Decision decide_from_sample(const double st[7], uint64_t tiles, const fr_kparams &p, int precision) {
+static Decision decide_from_sample(const double st[7], uint64_t tiles, const fr_kparams &p, int precision, bool two_pass_ok) {
     const double lanes = 64.0 * st[2];
     const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes, handed = st[4] / lanes;
     Decision d{2, false, 0u};
-    if (tiles >= kSampleMinTiles) {
+    if (tiles >= kMidRuleTiles) {
         if (capped >= 0.10 && waste < 0.01)
             d.choice = 0; /* long orbits dominate and tiles stay full: the strip kernel's ground */
         else if (handed >= 0.002 || (handed * (double)p.ncols * (double)p.nrows >= 4096.0 && st[6] >= 128.0 * st[4]))
@@ -678,16 +679,28 @@ static Decision decide_from_sample(const double st[7], uint64_t tiles, const fr_
         d.one_band = mean >= 128.0;
         return d;
     }
-    /* GUI-sized launches (profiles/r04_kernel_choice_midsize.txt) */
-    (void)precision;
-    if (handed >= 0.05 && waste >= 0.5) {
-        d.choice = 1; /* a dust: most tiles thin out early and their stragglers are long — the lists pay even here */
-        d.strip_tiles = 4;
-    } else if (mean < 32.0) {
-        d.choice = 2; /* short orbits: the first pass's per-tile overhead is a third of the strip kernel's */
-        d.strip_tiles = 4;
+    /* Launches under 8192 x 4096 — every frame a GUI asks for (profiles/r04_kernel_choice_midsize.txt, 13 views x 2 precisions
+     * at 1920 x 1080, 2048^2, 3840 x 2160, 4096^2).  What decides at these sizes is filling and balancing the chip, so the
+     * one-tile strip kernel (the by-size default) is the best or within a few per cent on every view but two kinds: */
+    if (capped < 0.001 && ((mean < 16.0 && handed < 0.002) || (mean < 32.0 && waste < 1.0 && tiles >= 100000))) {
+        /* short orbits everywhere and no long stragglers (thin dusts, exteriors with no piece of the set in them; from
+         * 3840 x 2160 up also Julia sets of a couple of dozen iterations): per-tile overhead is all there is, and the first
+         * pass's is a third of the strip kernel's (3840 x 2160 thin dust: 0.040 ms against 0.050 for 4-tile and 0.069 for
+         * 1-tile strips; julia 0.285+0.01i there: 0.065 against 0.081).  Strip length: 7 tiles for the very shortest orbits
+         * and from 4096^2 up, 4 below.  A constant the scaled loop may not run with (the dendrite c = i) takes 4-tile strips of
+         * the strip kernel instead */
+        d.choice = two_pass_ok ? 2 : 0;
+        d.strip_tiles = !two_pass_ok ? 4u : (mean < 8.0 || tiles >= 200000) ? 7u : 4u;
+    } else if (two_pass_ok && handed >= 0.05 && waste >= 2.0 && tiles >= (precision == FR_PRECISION_F64 ? 60000u : 200000u)) {
+        /* a Julia dust: most tiles thin out within an episode and their stragglers are long — the lists pay from 2048^2 up
+         * in f64 (0.179 ms against 0.206 for 1-tile strips) and from 4096^2 up in f32 (0.268 against 0.350); below, the
+         * strips are level or ahead.  waste >= 2 keeps Mandelbrot filaments out (waste 1.0-1.6): their lists carry c and
+         * lose to strips by 2x */
+        d.choice = 1;
+        d.strip_tiles = tiles >= 200000 ? 7u : 4u;
     } else {
-        d.choice = 0; /* strips, their length by launch size as before */
+        d.choice = 0;
+        d.strip_tiles = 1;
     }
     return d;
 }
@@ -717,8 +730,9 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
     if (o.tile != 0 || !g_dispatch_sampling.load()) return -1;
     const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
     if (tiles < kAsyncMinTiles) return -1;
-    fr_kparams q = p; /* would two passes be possible at all? */
-    if (!fr_wants_two_pass(q, precision, 0, 1)) return -1;
+    fr_kparams q = p; /* would two passes be possible at all?  If not, the statistics still choose the strip length */
+    const bool two_pass_ok = fr_wants_two_pass(q, precision, 0, 1);
+    if (!two_pass_ok && (tiles >= kMidRuleTiles || (cfg->algo != FR_ALGO_MANDELBROT && cfg->algo != FR_ALGO_JULIA))) return -1;
     const uint64_t key = view_key(cfg, p, precision);
     int slot_idx = -1;
     {
@@ -735,7 +749,7 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
                 if (st[1] <= 0.0 || st[0] <= 0.0) {
                     v.state = 2, v.two_pass = -1;
                 } else {
-                    const Decision d = decide_from_sample(st, tiles, p, precision);
+                    const Decision d = decide_from_sample(st, tiles, p, precision, two_pass_ok);
                     v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles;
                     v.lane_fraction = st[0] / st[1];
                 }
@@ -770,7 +784,7 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
         v.state = 0, v.key = 0;
         return -1;
     }
-    const Decision d = decide_from_sample(st, tiles, p, precision);
+    const Decision d = decide_from_sample(st, tiles, p, precision, two_pass_ok);
     v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles, v.lane_fraction = st[0] / st[1];
     *one_band = d.one_band;
     *strip_tiles = d.strip_tiles;

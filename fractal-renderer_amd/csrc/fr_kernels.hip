@@ -3239,7 +3239,13 @@ hipError_t launch_precision(const fr_kparams &p, int mode, const fr_kout &out, i
             }
         }
         /* p.strip_tiles: the length the view's own statistics call for (fr_api.hip: choose_kernel); else by launch size */
-        const uint32_t k_len = (mode == FR_OUT_RGB && p.strip_tiles) ? p.strip_tiles : tiles >= 262144 ? 7u : tiles >= 65536 ? 4u : tiles >= 16384 ? 2u : 1u;
+        /* By size (round 4, tools/strip_length_study.py -> profiles/r04_strip_length_by_size.txt): ONE tile per workgroup up to
+         * 4096^2 — below that a launch has too few workgroups for longer strips to fill and balance the chip's 8192 wave
+         * slots (1920 x 1080, default view, f64: 0.122 ms against 0.158 / 0.244 / 0.294 for 2 / 4 / 7 tiles; still 13-23 %
+         * at 4096^2) — and the longest strips from 8192 x 4096 up, where the per-workgroup costs they amortise are what is
+         * left (8192^2: 7 tiles best on six views of eight).  Views of very short orbits prefer long strips at every size;
+         * the view's statistics say so from the second frame on (strip_tiles). */
+        const uint32_t k_len = (mode == FR_OUT_RGB && p.strip_tiles) ? p.strip_tiles : tiles >= 524288 ? 7u : 1u;
         if (k_len >= 7u) {
             name = FR_KNAME("escape_strip_kernel", "7 tiles");
             return launch_strips<T, 7>(p, mode, out, stream);
@@ -3525,7 +3531,7 @@ bool fr_wants_two_pass(fr_kparams &p, int precision, int tile, int hint) {
          * f64, against the strips the default would otherwise pick): 65 536 tiles 0.17 / 0.21 ms against 0.18 / 0.30,
          * 131 072 tiles 0.17 / 0.22 against 0.20 / 0.33; at 32 768 tiles and below the strips win in f32 */
         const uint64_t tiles = (((uint64_t)p.ncols + 7) / 8) * (((uint64_t)p.nrows + 7) / 8);
-        if (tiles < 65536 && hint < 1) return false; /* (a MEASURED view may ask for them from 4096 tiles up) */
+        if (tiles < 262144 && hint < 1) return false; /* (a MEASURED view may ask for them from 4096 tiles up) */
         if (tiles < 4096) return false;
         /* which of the two suits the IMAGE is measured where that pays (hint: 1 two passes, 0 strips — fr_api.hip:
          * choose_kernel); without a measurement, by the algorithm: Julia views are mostly short orbits with a heavy tail */

@@ -213,6 +213,8 @@ int fr_render_rgb8_multi(const fr_config *cfg, int precision, uint32_t block_row
  *   FR_GATHER_PEER_COPY  peer-to-peer DMA (hipMemcpyPeerAsync), works for repeated device indices too;
  *   FR_GATHER_RCCL       grouped ncclSend / ncclRecv on a communicator from ncclCommInitAll
  *                        (librccl is loaded on first use; needs distinct devices). */
+/* The call renders on streams of the library's own and returns when the image is complete: work the CALLER has queued on
+ * d_out on a stream of its own (a fill, an earlier reader) must have finished before the call. */
 typedef enum fr_gather { FR_GATHER_PEER_COPY = 0, FR_GATHER_RCCL = 1 } fr_gather;
 int fr_render_rgb8_multi_device(const fr_config *cfg, int precision, uint32_t block_rows, int gather, void *d_out,
                                 size_t out_len);
@@ -313,9 +315,10 @@ int fr_last_kernel_ms(float *ms);
 int fr_last_kernel_name(char *buf, size_t buf_len);
 
 /* Kernel-variant selector for tuning studies and tests; every variant produces the same bytes.
- * 0 = default: strips of 8x8 tiles (strip length 1 / 2 / 4 / 7 tiles by launch size) unless the view's own statistics call for
- *     another kernel — see fr_set_dispatch_sampling; without statistics (the first frame of a GUI-sized view, sampling
- *     off): two passes (11) for Julia images of 65 536 tiles and more with a cap of 512 and more, strips otherwise;
+ * 0 = default: strips of 8x8 tiles (one tile per workgroup under 8192 x 4096 pixels, seven from there up) unless the view's
+ *     own statistics call for another kernel or strip length — see fr_set_dispatch_sampling; without statistics (the first
+ *     frame of a GUI-sized view, sampling off): two passes (11) for Julia images of 4096^2 pixels and more with a cap of
+ *     512 and more, strips otherwise;
  * 1, 2, 4 = the strip kernel with a fixed strip length of 1, 2, 4 tiles, 8 = of 7 tiles (the longest);
  * 9 = 7-tile strips with lane refill;
  * 10 = the work-queue kernel (persistent waves drawing 64x32-pixel patches from a device-wide counter, unchecked
@@ -348,9 +351,14 @@ int fr_set_tile(int tile);
  *   on a stream of the library's own, and the calling thread waits for it (~40 us): the ONE step of the device-pointer entry
  *   points that blocks.  Rule: capped >= 0.10 and waste < 0.01 -> strips; else handed >= 0.002 (or >= 4096 handed-over
  *   pixels with >= 128 iterations to go on average) -> two passes; else the first pass alone.
+ *   (Launches under 524 288 tiles, 8192 x 4096, use the rule of the next paragraph instead.)
  *   Launches of 4096 .. 131 072 tiles — every frame the reference's GUI asks for (src/gui.rs:56-82) — NEVER block: the first
- *   frame of a view is dispatched by algorithm and size as described under fr_set_tile, the sample is enqueued BEHIND its
- *   render, and the next frame of the same view is dispatched from the measured numbers (rule: DESIGN.md 3.2d).
+ *   frame of a view is dispatched by size as described under fr_set_tile, the sample is enqueued BEHIND its render, and the
+ *   next frame of the same view is dispatched from the measured numbers.  Rule: capped < 0.001 and either mean < 16 with
+ *   handed < 0.002 (orbits of a dozen iterations everywhere) or, from 100 000 tiles up, mean < 32 with waste < 1 -> the first
+ *   pass alone (4- or 7-tile strips; 4-tile strips of the strip kernel for a Julia constant the scaled loop may not use);
+ *   handed >= 0.05 and waste >= 2 (a Julia dust) from 60 000 tiles up in f64, 200 000 in f32 -> two passes; everything else
+ *   -> one-tile strips.
  * A view is identified by the fields that determine orbits (algo, width, height, iterations, limit, pos, scale, julia_set),
  * the launch's rows and the precision: changing colours, exposure, smooth or inside keeps it.  The last 32 views are
  * remembered.  No sample is taken while `hip_stream` is being captured into a graph.  0 switches sampling off (dispatch

@@ -142,6 +142,7 @@ def test_c5_through_eight_logical_devices_host_sink_and_peer_gather(fr):
         nbytes = 3 * ocfg.width * ocfg.height
         d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         d.zero_()
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the library's own: order them
         _native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), int(prec), 0, _native.FR_GATHER_PEER_COPY,
                                                       C.c_void_p(d.data_ptr()), nbytes))
         torch.cuda.synchronize()

@@ -234,9 +234,10 @@ def test_two_pass_render_matches_the_oracle(fr, lib, case):
 
 
 def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, lib):
-    """Five host threads, each on its own stream, render Julia images large enough for the default dispatch to
-    take two passes (>= 65 536 tiles, caps of 512 and more): they contend for the context's three survivor-list buffers and sixteen
-    counter slots.  Then the host-buffer entry point, which renders the image in bands on two streams."""
+    """Five host threads, each on its own stream, render Julia images in two passes (tile 11: since round 4 the default
+    dispatch takes them at this size only for views whose measured statistics call for them): they contend for the context's
+    three survivor-list buffers and sixteen counter slots.  Then the host-buffer entry point, which renders the image in bands
+    on two streams."""
     import threading
 
     import torch
@@ -261,8 +262,9 @@ def test_two_pass_render_from_concurrent_threads_and_through_the_host_path(fr, l
             for rep in range(12):
                 with torch.cuda.stream(stream):
                     out.zero_()
-                    _native.check(lib.fr_render_rows_rgb8_device(C.byref(cfgs[i]), precs[i], 0, 2048, out.data_ptr(), out.numel(),
-                                                                 stream.cuda_stream))
+                    o = fr.RenderOpts(tile=11)
+                    _native.check(lib.fr_render_rows_rgb8_device_opts(C.byref(cfgs[i]), precs[i], 0, 2048, out.data_ptr(), out.numel(),
+                                                                      stream.cuda_stream, C.byref(o)))
                 stream.synchronize()
                 _native.check(lib.fr_last_kernel_name(name, len(name)))
                 if not name.value.startswith(b"escape_first_kernel"):
@@ -479,14 +481,17 @@ def test_default_dispatch_chooses_the_kernel_from_a_sample_of_the_image(fr, lib)
 
     from fractal_renderer_amd import _native
 
-    w, h = 4096, 2048  # exactly 131 072 tiles
+    w, h = 4096, 2048  # exactly 131 072 tiles: the blocking sample, the rule of launches under 8192 x 4096
     views = [
-        ("julia dust", dict(algo=O.JULIA, iterations=4096, julia_set=(-0.8, 0.156)), b"escape_first_kernel"),
-        # (the default frame at 2:1 sits between the rules: whichever kernel is chosen, the bytes are what is checked)
-        ("mandelbrot default", dict(algo=O.MANDELBROT, iterations=1024), (b"escape_strip_kernel", b"escape_first_kernel")),
+        # a dust: two passes in f64 (4-tile first pass), one-tile strips in f32
+        ("julia dust", dict(algo=O.JULIA, iterations=4096, julia_set=(-0.8, 0.156)), (b"escape_first_kernel + escape_second_kernel<double, 4-tile",
+                                                                                      b"escape_strip_kernel<float, 1 tile")),
+        ("mandelbrot default", dict(algo=O.MANDELBROT, iterations=1024), (b"escape_strip_kernel<float, 1 tile", b"escape_strip_kernel<double, 1 tile")),
+        # orbits of a dozen iterations everywhere: the first pass alone, 7-tile strips
         ("mandelbrot exterior", dict(algo=O.MANDELBROT, iterations=4096, pos=(-1.9, 0.15), scale=(4.0, 4.0)), b"escape_first_kernel<"),
+        # short orbits too, but the first pass cannot run this constant: the strip kernel with 4-tile strips
         ("julia dendrite (c.re = 0: the scaled loop is not admissible)", dict(algo=O.JULIA, iterations=512, julia_set=(0.0, 1.0)),
-         b"escape_strip_kernel"),
+         (b"escape_strip_kernel<float, 4 tiles", b"escape_strip_kernel<double, 4 tiles")),
     ]
     name = C.create_string_buffer(256)
     out = torch.empty(w * h * 3, dtype=torch.uint8, device="cuda")

@@ -80,6 +80,7 @@ def test_multi_gather_into_device_memory(fr, lib, devices, gather):
         cfg, _ = cfg_of(fr, width, height, iters or 200)
         want = fr.get_image(cfg)
         d_out = torch.zeros(height * width * 3, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()  # the fill is on torch's stream, the render on the library's own
         rc = lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, block_rows, gather, d_out.data_ptr(), d_out.numel())
         if gather == _native.FR_GATHER_RCCL and len(devices) > 1:
             # a communicator cannot hold one GPU twice: the call must say so, not hang
@@ -130,6 +131,7 @@ def test_multi_large_julia_takes_two_passes_per_device_chunk(fr, lib):
     torch.cuda.synchronize()
     assert torch.equal(torch.from_numpy(got).reshape(-1), single.cpu())
     d_out = torch.zeros(8192 * 16384 * 3, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
     _native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 0, _native.FR_GATHER_PEER_COPY, d_out.data_ptr(), d_out.numel()))
     assert torch.equal(d_out, single)
     st = fr.multi_stats()
@@ -261,8 +263,9 @@ def test_last_kernel_name_reports_what_ran(fr, lib):
     s = torch.cuda.current_stream()
     _native.check(lib.fr_set_profiling(1))
     try:
-        # (4096^2: the default dispatch samples the view; Julia dust goes to the first-pass kernel, with or without lists)
-        for algo, expect in [(0, (b"escape_strip_kernel<double", b"escape_first_kernel<double")), (O.JULIA, b"escape_first_kernel")]:
+        # (4096^2: the default dispatch samples the view and picks among the strip kernel and the first-pass kernel, with or
+        # without lists — whichever it is, the name reported is the kernel that ran)
+        for algo, expect in [(0, (b"escape_strip_kernel<double", b"escape_first_kernel")), (O.JULIA, (b"escape_strip_kernel<double", b"escape_first_kernel"))]:
             cfg, _ = cfg_of(fr, 4096, 4096, 100, algo=algo, julia_set=(-0.8, 0.156))
             d = torch.empty(4096 * 4096 * 3, dtype=torch.uint8, device="cuda:0")
             _native.check(lib.fr_render_rows_rgb8_device(C.byref(cfg), 0, 0, 4096, d.data_ptr(), d.numel(), s.cuda_stream))
@@ -347,6 +350,7 @@ def test_multi_device_failure_drains_and_recovers(fr, lib, sink):
             rc = lib.fr_render_rgb8_multi(C.byref(cfg), 0, 64, out.ctypes.data, out.nbytes)
         else:
             d = torch.zeros(out.nbytes, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
             rc = lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 64, 0, C.c_void_p(d.data_ptr()), d.numel())
         assert rc == 4, (dev, chunk, rc)  # FR_ERR_HIP
         msg = lib.fr_last_error().decode()
@@ -379,6 +383,7 @@ def test_multi_device_failure_rccl_sink_needs_two_gpus(fr, lib):
         assert "injected failure" in lib.fr_last_error().decode()
         _native.check(lib.fr_debug_inject_multi_failure(-1, 0))
         d.zero_()
+        torch.cuda.synchronize()
         _native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, 64, 1, C.c_void_p(d.data_ptr()), d.numel()))
         assert np.array_equal(d.cpu().numpy().reshape(want.shape), want), (dev, chunk)
     fr.init_devices([0])
