@@ -181,7 +181,21 @@ int Ctx::create(int device) {
             (void)hipGetLastError();
             rgb = Scratch();
         }
+        (void)reserve_stage((size_t)40 << 20); /* the pinned staging buffer of GUI-sized host renders; lazily otherwise */
     }
+    return FR_OK;
+}
+
+int Ctx::reserve_stage(size_t bytes) {
+    if (bytes <= stage_cap) return FR_OK;
+    if (stage) (void)hipHostFree(stage);
+    stage = nullptr, stage_cap = 0;
+    const hipError_t e = hipHostMalloc(&stage, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        stage = nullptr;
+        return fail_hip(e, "hipHostMalloc(staging buffer)");
+    }
+    stage_cap = bytes;
     return FR_OK;
 }
 
@@ -210,6 +224,10 @@ void Ctx::destroy() {
     }
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
+    if (copy_pool) destroy_copy_pool(copy_pool);
+    copy_pool = nullptr;
+    if (stage) (void)hipHostFree(stage);
+    stage = nullptr, stage_cap = 0;
     for (hipStream_t *st : {&aux_stream, &aux2_stream})
         if (*st) (void)hipStreamSynchronize(*st); /* a sample in flight writes to sample_result */
     if (sample_counters) (void)hipFree(sample_counters);

@@ -130,6 +130,13 @@ struct Ctx {
     std::condition_variable slot_cv; /* a slot of either ring was released */
     unsigned palette_next = 0, surv_next = 0;
 
+    /* GUI-sized host-buffer renders (fr_host.hip: host_render_staged): a pinned staging buffer of the library's own — the
+     * device never maps, pins or DMAs into the CALLER's pages for frames up to 3840 x 2160 RGBA — and a few copy threads */
+    void *stage = nullptr;
+    size_t stage_cap = 0;
+    struct CopyPool *copy_pool = nullptr;
+    int reserve_stage(size_t bytes);
+
     int create(int device); /* hipSetDevice + streams; the calling thread stays on `device` */
     void destroy();         /* frees everything (caller made sure nothing is in flight) */
     int reserve(Scratch &s, size_t bytes);
@@ -213,6 +220,7 @@ class ChunkPinner {
     std::vector<uint8_t *> regs_;
 };
 void prefault(void *ptr, size_t len);
+void destroy_copy_pool(CopyPool *pool); /* stops and joins the threads (fr_host.hip) */
 
 /* per-thread kernel timing (fr_set_profiling / fr_last_kernel_ms) */
 struct Profiling {

@@ -14,12 +14,24 @@
  * touch where the pages do not exist yet, pin, DMA behind the band that completes the chunk — so that
  * faulting, pinning, rendering and copying all overlap and the call costs about what the slowest of
  * them does.  Copies go straight to their final place: no staging, no second pass over the bytes.
+ *
+ * GUI-SIZED frames (up to 3840 x 2160 RGBA, round 4) take another road: host_render_staged.  The device DMAs into a
+ * pinned buffer of the LIBRARY's and the calling thread (with a few helpers for the larger frames) copies the bytes out —
+ * the caller's pages are never mapped, pinned or registered with the driver.  Why: the reference's GUI gets a fresh Vec
+ * from every get_image and drops it after the upload (src/gui.rs:56-82); pages that the driver had registered for DMA —
+ * by hipHostRegister here or by the runtime's own in-place pinning of a pageable copy — make the kernel driver
+ * revalidate the process's user-pointer mappings when they are unmapped, with the process's hardware queues stopped
+ * meanwhile (a 1 ms frame measured at 7-28 ms, profiles/r03_gui_fresh_buffer_pattern.txt).  Rendering, D2H and the copy
+ * out are pipelined in bands, so the second pass over the bytes costs little (profiles/r04_gui_staging.txt).
  */
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <immintrin.h>
+
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +52,7 @@ constexpr size_t kPage = 4096;
 constexpr size_t kHuge = (size_t)2 << 20;
 constexpr size_t kChunk = (size_t)64 << 20;
 constexpr size_t kPinThreshold = (size_t)16 << 20; /* below: one kernel + one plain copy */
+constexpr size_t kStageMax = (size_t)40 << 20;     /* up to a 3840 x 2160 RGBA frame (33.2 MB): the staged road */
 
 double now_ms() {
     using namespace std::chrono;
@@ -210,12 +223,234 @@ void ChunkPinner::release() {
 
 ChunkPinner::~ChunkPinner() { release(); }
 
+/* ---- the copy threads of the staged road ----------------------------------------------------------- */
+
+/* A few threads that sleep until the calling thread has bytes to move: a frame's band is cut into pieces, the caller
+ * takes the first and the helpers the rest.  kind 0: memcpy(dst, src, len); kind 1: first touch of [dst, dst + len). */
+struct CopyPool {
+    struct Piece {
+        uint8_t *dst;
+        const uint8_t *src;
+        size_t len;
+        int kind;
+    };
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable work_cv, done_cv;
+    std::vector<Piece> pieces;
+    size_t outstanding = 0;
+    bool stop = false;
+
+    explicit CopyPool(int helpers) {
+        for (int t = 0; t < helpers; t++) threads.emplace_back([this] { loop(); });
+    }
+    static void run(const Piece &p) {
+        if (p.kind == 0) memcpy(p.dst, p.src, p.len);
+        else prefault(p.dst, p.len);
+    }
+    void loop() {
+        for (;;) {
+            Piece p;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                work_cv.wait(lk, [&] { return stop || !pieces.empty(); });
+                if (pieces.empty()) return; /* stop */
+                p = pieces.back();
+                pieces.pop_back();
+            }
+            run(p);
+            std::lock_guard<std::mutex> lk(m);
+            if (--outstanding == 0) done_cv.notify_all();
+        }
+    }
+    /* hand out pieces; returns at once (the caller works on its own piece, then calls wait()) */
+    void post(const std::vector<Piece> &ps) {
+        if (ps.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (const Piece &p : ps) pieces.push_back(p);
+            outstanding += ps.size();
+        }
+        work_cv.notify_all();
+    }
+    /* the caller helps with whatever is still queued, then waits for the pieces in flight */
+    void wait() {
+        for (;;) {
+            Piece p;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (pieces.empty()) break;
+                p = pieces.back();
+                pieces.pop_back();
+            }
+            run(p);
+            std::lock_guard<std::mutex> lk(m);
+            --outstanding;
+        }
+        std::unique_lock<std::mutex> lk(m);
+        done_cv.wait(lk, [&] { return outstanding == 0; });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        work_cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+
+void destroy_copy_pool(CopyPool *pool) { delete pool; }
+
+namespace {
+
+bool staging_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("FR_HOST_STAGING"); /* tuning aid: 0 = round 3's road for GUI-sized frames too */
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
+int copy_helpers() {
+    static const int n = [] {
+        const char *e = getenv("FR_COPY_THREADS");
+        if (e && atoi(e) >= 1) return atoi(e) > 16 ? 15 : atoi(e) - 1;
+        const long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        return (int)(cpus >= 8 ? 3 : cpus >= 4 ? 1 : 0);
+    }();
+    return n;
+}
+
+/* wait for an event with little latency: poll for a while (the DMA of a band takes tens of microseconds), then sleep */
+hipError_t wait_event(hipEvent_t e) {
+    const double t0 = now_ms();
+    for (;;) {
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        for (int k = 0; k < 32; k++) _mm_pause();
+        if (now_ms() - t0 > 0.5) return hipEventSynchronize(e);
+    }
+}
+
+}  // namespace
+
+/* GUI-sized frames: render in up to four bands of whole 8-row tiles on two streams, DMA each finished band into the
+ * library's pinned staging buffer, copy it out to the caller's buffer while the next band renders and travels. */
+int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts &o, uint32_t y0, uint32_t y1, uint8_t *out,
+                       unsigned bpp) {
+    const size_t row_bytes = (size_t)bpp * cfg->width;
+    const size_t need = row_bytes * (size_t)(y1 - y0);
+    int rc = ctx.reserve(ctx.rgb, need);
+    if (rc != FR_OK) return rc;
+    uint8_t *scratch = static_cast<uint8_t *>(ctx.rgb.ptr);
+    uint8_t *stage = static_cast<uint8_t *>(ctx.stage);
+    const bool trace = trace_enabled();
+    const double t_start = now_ms();
+
+    /* bands: ~6 MiB each, at most four (a 3840 x 2160 RGB frame: four of 6.2 MB; 1920 x 1080: two; 750 x 500: one) */
+    const uint32_t rows = y1 - y0;
+    uint32_t nb = (uint32_t)((need + ((size_t)6 << 20) - 1) / ((size_t)6 << 20));
+    if (need >= ((size_t)3 << 20) && nb < 2) nb = 2;
+    if (nb > 4) nb = 4;
+    if (nb < 1) nb = 1;
+    uint32_t band_rows = ((rows + nb - 1) / nb + 7u) & ~7u;
+    if (band_rows == 0) band_rows = 8;
+    nb = (rows + band_rows - 1) / band_rows;
+
+    Opts ob = o;
+    decide_kernel(ctx, cfg, precision, y0, y1, ob, ctx.stream, true); /* ONE view (and one sample) for the frame, not one per band */
+    const int pending_sample = ob.pending_sample;
+    ob.pending_sample = -1;
+    auto render_on = [&](hipStream_t st, uint32_t ya, uint32_t yb, uint8_t *dst) -> int {
+        fr_kparams p;
+        fill_params(cfg, ob, p);
+        p.nrows = yb - ya;
+        p.y_first = ya;
+        p.block_rows = p.nrows;
+        p.y_stride = 0;
+        p.out_rgba = bpp == 4 ? 1u : 0u;
+        return render_device(ctx, cfg, p, precision, ob, dst, st);
+    };
+
+    hipError_t err = hipSuccess;
+    const char *what = "";
+    hipStream_t last = ctx.stream;
+    for (uint32_t b = 0; b < nb && rc == FR_OK && err == hipSuccess; b++) {
+        const uint32_t ya = y0 + b * band_rows, yb = ya + band_rows < y1 ? ya + band_rows : y1;
+        const size_t a = row_bytes * (size_t)(ya - y0), len = row_bytes * (size_t)(yb - ya);
+        hipStream_t st = (b & 1) ? ctx.stream2 : ctx.stream;
+        last = st;
+        rc = render_on(st, ya, yb, scratch + a);
+        if (rc != FR_OK) break;
+        hipEvent_t ek, ec;
+        rc = ctx.event(2 * b, &ek);
+        if (rc == FR_OK) rc = ctx.event(2 * b + 1, &ec);
+        if (rc != FR_OK) break;
+        if ((err = hipEventRecord(ek, st)) != hipSuccess) what = "hipEventRecord";
+        else if ((err = hipStreamWaitEvent(ctx.copy_stream, ek, 0)) != hipSuccess) what = "hipStreamWaitEvent";
+        else if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, ctx.copy_stream)) != hipSuccess) what = "hipMemcpyAsync";
+        else if ((err = hipEventRecord(ec, ctx.copy_stream)) != hipSuccess) what = "hipEventRecord";
+    }
+    ctx.post_sample(pending_sample, last); /* a first frame of the view: its statistics, behind the last band */
+    const double t_enqueued = now_ms();
+
+    /* the copy out: the caller alone for small bands, with the helpers from 2 MiB a band; pages the caller has never
+     * touched (a fresh Vec) are faulted in — huge-page hint, all threads — while the first band renders */
+    const int helpers = need >= ((size_t)3 << 20) ? copy_helpers() : 0;
+    if (helpers > 0 && !ctx.copy_pool) ctx.copy_pool = new CopyPool(helpers);
+    CopyPool *pool = helpers > 0 ? ctx.copy_pool : nullptr;
+    auto spread = [&](uint8_t *dst, const uint8_t *src, size_t len, int kind) {
+        if (!pool || len < ((size_t)1 << 20)) {
+            CopyPool::run(CopyPool::Piece{dst, src, len, kind});
+            return;
+        }
+        const size_t parts = (size_t)helpers + 1;
+        const size_t piece = ((len + parts - 1) / parts + 4095) & ~(size_t)4095;
+        std::vector<CopyPool::Piece> ps;
+        for (size_t off = piece; off < len; off += piece)
+            ps.push_back(CopyPool::Piece{dst + off, src ? src + off : nullptr, off + piece < len ? piece : len - off, kind});
+        pool->post(ps);
+        CopyPool::run(CopyPool::Piece{dst, src, piece < len ? piece : len, kind});
+        pool->wait();
+    };
+    if (rc == FR_OK && err == hipSuccess && need >= ((size_t)1 << 20) && !looks_resident(out, need)) spread(out, nullptr, need, 1);
+    const double t_touched = now_ms();
+    for (uint32_t b = 0; b < nb && rc == FR_OK && err == hipSuccess; b++) {
+        const uint32_t ya = y0 + b * band_rows, yb = ya + band_rows < y1 ? ya + band_rows : y1;
+        const size_t a = row_bytes * (size_t)(ya - y0), len = row_bytes * (size_t)(yb - ya);
+        hipEvent_t ec;
+        rc = ctx.event(2 * b + 1, &ec);
+        if (rc != FR_OK) break;
+        if ((err = wait_event(ec)) != hipSuccess) {
+            what = "waiting for a band's DMA";
+            break;
+        }
+        spread(out + a, stage + a, len, 0);
+    }
+    /* drain whatever an error left in flight: the scratch and the staging buffer are reused by the next call */
+    if (rc != FR_OK || err != hipSuccess) {
+        (void)hipStreamSynchronize(ctx.stream);
+        (void)hipStreamSynchronize(ctx.stream2);
+        (void)hipStreamSynchronize(ctx.copy_stream);
+    }
+    if (trace)
+        fprintf(stderr, "[fr_host] staged %zu bytes in %u bands: enqueued at %.3f ms, first touch until %.3f, copied out at %.3f\n", need, nb,
+                t_enqueued - t_start, t_touched - t_start, now_ms() - t_start);
+    if (rc != FR_OK) return rc;
+    if (err != hipSuccess) return fail_hip(err, what);
+    return FR_OK;
+}
+
 /* ---- rows [y0, y1) into a host buffer ----------------------------------------------------------- */
 
 int host_render_rows(Ctx &ctx, const fr_config *cfg, int precision, const Opts &o, uint32_t y0, uint32_t y1,
                      uint8_t *out, unsigned bpp) {
     const size_t row_bytes = (size_t)bpp * cfg->width;
     const size_t need = row_bytes * (size_t)(y1 - y0);
+    /* GUI-sized frames: through the library's own pinned staging buffer (the caller's pages are never registered) */
+    if (need <= kStageMax && staging_enabled() && ctx.reserve_stage(need > ((size_t)40 << 20) ? need : (size_t)40 << 20) == FR_OK)
+        return host_render_staged(ctx, cfg, precision, o, y0, y1, out, bpp);
     int rc = ctx.reserve(ctx.rgb, need);
     if (rc != FR_OK) return rc;
     uint8_t *scratch = static_cast<uint8_t *>(ctx.rgb.ptr);

@@ -12,11 +12,15 @@ import numpy as np  # noqa: E402
 import fractal_renderer_amd as fr  # noqa: E402
 
 fr.init(0)
-for w, h in ((750, 500), (1920, 1080), (3840, 2160), (5000, 3000)):
+print("FR_HOST_STAGING=%s FR_COPY_THREADS=%s" % (os.environ.get("FR_HOST_STAGING", "(default: on)"), os.environ.get("FR_COPY_THREADS", "(default)")))
+for w, h in ((750, 500), (1500, 1000), (1920, 1080), (3840, 2160), (5000, 3000)):
     cfg = fr.Config.new()
-    cfg.width, cfg.height, cfg.iterations = w, h, 1024
+    cfg.width, cfg.height, cfg.iterations = w, h, 1024 if w > 1500 else 50
+    cfg.pos.re, cfg.exposure = -0.6, 5.0
     keep = np.ones((h, w, 3), dtype=np.uint8)
+    t0 = time.perf_counter()
     fr.get_image_rows(cfg, 0, h, fr.Precision.F64, out=keep)
+    first = (time.perf_counter() - t0) * 1e3
     same, fresh, lib_fresh = [], [], []
     for _ in range(100):
         t0 = time.perf_counter()
@@ -35,4 +39,4 @@ for w, h in ((750, 500), (1920, 1080), (3840, 2160), (5000, 3000)):
         lib_fresh.append((time.perf_counter() - t0) * 1e3)
         del img
     f = lambda v: "min %.2f med %.2f max %.2f" % (min(v), sorted(v)[len(v) // 2], max(v))
-    print("%dx%d (%.1f MB): same buffer %s | fresh touched buffer per call %s | get_image() %s" % (w, h, 3e-6 * w * h, f(same), f(fresh), f(lib_fresh)), flush=True)
+    print("%dx%d (%.1f MB): first call %.2f | same buffer %s | fresh touched buffer per call %s | get_image() %s" % (w, h, 3e-6 * w * h, first, f(same), f(fresh), f(lib_fresh)), flush=True)
