@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--block-rows", type=int, default=256)
     ap.add_argument("--gather", choices=["rccl", "peer"], default="rccl",
                     help="single-process N > 1: how finished blocks reach the first GPU")
+    ap.add_argument("--root-share", type=int, default=1, choices=[0, 1, 2, 4],
+                    help="N > 1: the share of ITS row blocks the sink (rank 0 / the first device) renders: 1 = all (plain cyclic "
+                         "dealing, default), 2 / 4 = a half / a quarter (the rest is dealt to the other ranks), 0 = none: it only "
+                         "receives.  Same bytes; what the first real multi-GPU run should try when rank 0 shows the longest step")
     ap.add_argument("--logical", action="store_true",
                     help="single-process N > 1 on fewer GPUs: N logical devices on GPU 0 (a plumbing check, "
                          "never a scaling number)")
@@ -151,7 +155,7 @@ def loop_mix(kernel_name):
     if "first_kernel" in kernel_name or "second_kernel" in kernel_name or "queue_kernel" in kernel_name:
         n, what = 6.75, ("scaled form in unchecked blocks of 4 iterations with a per-lane count: 24 arithmetic + |z|^2 <= T test + "
                          "count + freeze per block = 27 / 4")
-    elif "strip_kernel" in kernel_name or "refill_kernel" in kernel_name:
+    elif "strip_kernel" in kernel_name or "refill_kernel" in kernel_name or "escape kernels" in kernel_name:
         n, what = 6.5, ("scaled form X = 2re, Y = 2im, A = X^2, B = Y^2: 6 per iteration + one distance add and one compare per "
                         "block of 4 = 26 / 4 (the reference as written: 8 arithmetic + 1 compare = 9)")
     else:
@@ -640,6 +644,7 @@ def run_in_library(args, torch, fr, lib, native):
     torch.cuda.set_device(devices[0])
     fr.init(devices[0])
     fr.init_devices(devices)
+    native.check(lib.fr_set_multi_root_share(args.root_share))
     prec = fr.Precision.F32 if args.precision == "f32" else fr.Precision.F64
     edge = workload_edge(args, world)
     cfg = make_config(fr, args.view, edge, args.iterations)
@@ -696,6 +701,20 @@ def run_in_library(args, torch, fr, lib, native):
         "mpixels_per_sec": pixels * args.steps / dt / 1e6,
         "pixel_iterations_per_image": total,
         "per_device_kernel_ms": st["kernel_ms"],
+        "root_share": args.root_share,
+        "per_device": {
+            "devices": [{"device": d, "rows": st["rows"][d], "launches": st["kernels"][d], "kernel_ms": st["kernel_ms"][d],
+                         "transfer_span_ms": st["transfer_span_ms"][d], "job_ms": st["job_ms"][d],
+                         "idle_ms": max(st["job_ms"][d] - st["kernel_ms"][d], 0.0), "bytes_moved": st["bytes_moved"][d],
+                         "link_GBps": st["bytes_moved"][d] / (st["transfer_span_ms"][d] * 1e-3) / 1e9 if st["transfer_span_ms"][d] > 0 else None}
+                        for d in range(world)],
+            "call_wall_ms": st["wall_ms"],
+            "note": "the LAST timed step (fr_multi_last_stats), ms: kernel_ms = the device's chunk kernels summed (HIP events); "
+                    "transfer_span_ms = device time from its first transfer being ready to its last one done; job_ms = host wall "
+                    "time of the device's thread, first launch to streams drained; bytes_moved = what its link to the first "
+                    "device carried",
+            "prediction": multi_gpu_prediction(world, pixels, total),
+        },
         "build_id": fr.build_id(),
         "roofline": dict(roofline_block(args.precision, total / world, kmax, pixels // world,
                                         "escape kernels of the slowest device's share (summed over its chunk launches)",
@@ -709,6 +728,25 @@ def run_in_library(args, torch, fr, lib, native):
     if logical:
         out["note"] = "logical devices share ONE GPU: this line checks the plumbing and is not a scaling measurement"
     print(json.dumps(out), flush=True)
+
+
+def multi_gpu_prediction(world, pixels, total_px_it):
+    """DESIGN.md §4's prediction for this workload at `world` GPUs, next to the measured per-rank fields, so that the first
+    real run can be read against it.  Inputs: the single-GPU rate of the default bench line (5.2e12 px-it/s, C2) and
+    ~50 GB/s one way over ONE xGMI link (MI355X_MICROARCH.md: 7 links x ~153 GB/s raw per GPU; a single peer-to-root
+    stream sustains about a third of a link's raw rate).  A PREDICTION: nothing here was measured on more than one GPU."""
+    if world <= 1:
+        return None
+    render_ms = total_px_it / 5.2e12 / world * 1e3
+    bytes_per_peer = 3.0 * pixels / world
+    link_ms = bytes_per_peer / 50e9 * 1e3
+    step_ms = max(render_ms, link_ms) + 0.25 * min(render_ms, link_ms)  # pipelined in chunks: the shorter leg mostly hides
+    ideal = total_px_it / 5.2e12 * 1e3 / world
+    return {"render_ms_per_rank": render_ms, "bytes_per_peer": bytes_per_peer, "link_ms_per_peer_at_50GBps": link_ms,
+            "predicted_step_ms": step_ms, "predicted_scaling_efficiency": ideal / step_ms,
+            "bound": "gather (each peer's link)" if link_ms > render_ms else "render",
+            "note": "prediction from single-GPU measurements (DESIGN.md 4); compare per_rank.ranks[*].transfer_span_ms with "
+                    "link_ms_per_peer and kernel_ms with render_ms_per_rank; if rank 0's step is the longest, try --root-share 2"}
 
 
 def run_distributed(args, torch, fr, lib, native, world, rank, local_rank):
@@ -726,7 +764,7 @@ def run_distributed(args, torch, fr, lib, native, world, rank, local_rank):
     cfg = make_config(fr, args.view, edge, args.iterations)
     row_bytes = 3 * cfg.width
     B = args.block_rows
-    renderer = P.DistributedRenderer(cfg, prec, B, device=device)
+    renderer = P.DistributedRenderer(cfg, prec, B, device=device, root_share=args.root_share)
     stream = torch.cuda.current_stream(device)
 
     def fence():
@@ -747,16 +785,31 @@ def run_distributed(args, torch, fr, lib, native, world, rank, local_rank):
     dt = float(t.item())
     # the dominant kernel's duration for the roofline: this rank's whole share as ONE launch, timed
     # with HIP events outside the timed region (the step itself launches per chunk of blocks)
-    share = torch.empty(max(P.local_rows(cfg.height, B, rank, world) * row_bytes, 1), dtype=torch.uint8, device=device)
+    # one more step, outside the timed region, with device events around every chunk kernel and every step's transfers:
+    # where each rank's time goes (the first real N > 1 run should be diagnostic)
+    renderer.render(diagnose=True)
+    fence()
+    report = renderer.step_report()
+    reports = [None] * world
+    dist.all_gather_object(reports, report)
+    rows_mine = P.local_rows(cfg.height, B, rank, world, args.root_share)
+    share = torch.empty(max(rows_mine * row_bytes, 1), dtype=torch.uint8, device=device)
     native.check(lib.fr_set_profiling(1))
     kernel_ms = []
-    for _ in range(3):
-        P.render_local_hip(cfg, prec, B, rank, world, share, stream.cuda_stream)
-        ms = C.c_float(0)
-        native.check(lib.fr_last_kernel_ms(C.byref(ms)))
-        kernel_ms.append(ms.value)
     name = C.create_string_buffer(160)
-    native.check(lib.fr_last_kernel_name(name, len(name)))
+    name.value = b"(this rank renders nothing: --root-share 0)"
+    for _ in range(3):
+        tot = 0.0
+        for first, stride in P.shares(rank, world, args.root_share):
+            rows = C.c_uint64(0)
+            native.check(lib.fr_render_block_cyclic_rgb8_device(C.byref(cfg), int(prec), B, first, stride, share.data_ptr(), share.numel(),
+                                                                stream.cuda_stream, C.byref(rows)))
+            if rows.value:
+                ms = C.c_float(0)
+                native.check(lib.fr_last_kernel_ms(C.byref(ms)))
+                tot += ms.value
+                native.check(lib.fr_last_kernel_name(name, len(name)))
+        kernel_ms.append(tot)
     del share
     y0 = cfg.height * rank // world
     y1 = cfg.height * (rank + 1) // world
@@ -790,6 +843,17 @@ def run_distributed(args, torch, fr, lib, native, world, rank, local_rank):
             "roofline": dict(roofline_block(args.precision, total / world, kavg, pixels // world,
                                             name.value.decode() + " over one rank's whole share (slowest rank)", None),
                              note=ROOFLINE_NOTE),
+            "root_share": args.root_share,
+            "per_rank": {
+                "ranks": reports,
+                "note": "ONE extra step after the timed ones, device events on each rank (ms): kernel_ms = its chunk kernels summed; "
+                        "compute_span_ms = first kernel start to last kernel end; transfer_ms = its grouped RCCL point-to-point "
+                        "calls on the communication stream (sends on a peer, receives on rank 0), summed; step_ms = the step on "
+                        "the device; idle_ms = step - compute span.  bytes_sent is what the rank's xGMI link to rank 0 carried.",
+                "link_GBps": [r["bytes_sent"] / (r["transfer_span_ms"] * 1e-3) / 1e9 if r and r["transfer_span_ms"] > 0 else None
+                              for r in reports],
+                "prediction": multi_gpu_prediction(world, pixels, total),
+            },
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

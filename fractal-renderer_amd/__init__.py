@@ -110,7 +110,8 @@ def multi_stats():
     _native.check(_native.load().fr_multi_last_stats(C.byref(st)))
     n = st.n_devices
     return {"n_devices": n, "kernels": list(st.kernels[:n]), "kernel_ms": list(st.kernel_ms[:n]),
-            "rows": list(st.rows[:n]), "wall_ms": st.wall_ms}
+            "rows": list(st.rows[:n]), "wall_ms": st.wall_ms, "transfer_span_ms": list(st.transfer_span_ms[:n]),
+            "job_ms": list(st.job_ms[:n]), "bytes_moved": list(st.bytes_moved[:n])}
 
 
 def init(device=-1):

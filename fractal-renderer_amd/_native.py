@@ -102,6 +102,9 @@ class fr_multi_stats(C.Structure):
         ("kernel_ms", C.c_float * FR_MAX_DEVICES),
         ("rows", C.c_uint64 * FR_MAX_DEVICES),
         ("wall_ms", C.c_double),
+        ("transfer_span_ms", C.c_float * FR_MAX_DEVICES),
+        ("job_ms", C.c_double * FR_MAX_DEVICES),
+        ("bytes_moved", C.c_uint64 * FR_MAX_DEVICES),
     ]
 
 
@@ -130,6 +133,7 @@ PROTOTYPES = {
     "fr_render_fern_rgb8": (C.c_int, [C.POINTER(fr_config), C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t]),
     "fr_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "fr_multi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "fr_set_multi_root_share": (C.c_int, [C.c_int]),
     "fr_render_rgb8_multi": (C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]),
     "fr_render_rgb8_multi_device": (
         C.c_int, [C.POINTER(fr_config), C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]),

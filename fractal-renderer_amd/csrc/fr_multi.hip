@@ -220,6 +220,43 @@ std::vector<std::pair<uint32_t, uint32_t>> chunk_schedule(uint32_t nb) {
     return ranges;
 }
 
+/* Who renders which row blocks (partition.py: shares / rank_chunks — the same dealing, so that both multi-GPU paths can be
+ * read against each other).  q = 1: block b -> device b % n.  q = 2, 4: the SINK (device 0, which also receives every other
+ * device's bytes) keeps every q-th of its blocks and the rest of them are dealt round-robin to the other devices; q = 0: the
+ * sink renders nothing.  Every share is a short list of arithmetic progressions (first block, stride): one progression is
+ * what one launch of the block-cyclic render covers. */
+struct Share {
+    uint32_t first, stride;
+};
+std::vector<Share> shares_of(uint32_t r, uint32_t n, int q) {
+    if (n == 1 || q == 1) return {Share{r, n}};
+    const uint32_t peers = n - 1;
+    if (r == 0) return q == 0 ? std::vector<Share>{} : std::vector<Share>{Share{0, (uint32_t)q * n}};
+    std::vector<Share> out{Share{r, n}};
+    if (q == 0) out.push_back(Share{(r - 1) * n, peers * n});
+    else
+        for (uint32_t c = 1; c < (uint32_t)q; c++) out.push_back(Share{(c + (uint32_t)q * (r - 1)) * n, (uint32_t)q * peers * n});
+    return out;
+}
+/* one launch: blocks first, first + stride, ... (count of them) */
+struct Chunk {
+    uint32_t first, stride, count;
+};
+std::vector<Chunk> rank_chunks(uint32_t r, uint32_t n, uint32_t nblocks, int q) {
+    std::vector<Chunk> out;
+    for (const Share &sh : shares_of(r, n, q)) {
+        if (sh.first >= nblocks) continue;
+        const uint32_t mine = (nblocks - sh.first + sh.stride - 1) / sh.stride;
+        /* the cuts of the LONGEST progression of this stride, so that devices one block short cut at the same places */
+        for (const auto &rg : chunk_schedule((nblocks + sh.stride - 1) / sh.stride)) {
+            const uint32_t j0 = rg.first, j1 = std::min(rg.second, mine);
+            if (j1 > j0) out.push_back(Chunk{sh.first + j0 * sh.stride, sh.stride, j1 - j0});
+        }
+    }
+    return out;
+}
+std::atomic<int> g_root_share{1};
+
 enum class Sink { Host, PeerCopy, Rccl };
 
 /* Host sink: the caller's buffer is made DMA-able in page-aligned 64 MiB chunks, front to back (every device's
@@ -307,6 +344,7 @@ struct Job {
     PinProgress *pins; /* Host sink only */
     DeviceSet *set;
     std::atomic<bool> *abort; /* a device failed: the others stop starting new work (RCCL: no new groups) */
+    int root_share;           /* see shares_of */
 };
 
 /* test aid (fr_debug_inject_multi_failure): logical device `g_inject_device` fails before its chunk
@@ -326,17 +364,37 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     const size_t row_bytes = (size_t)3 * j.cfg->width;
     const size_t need_total = row_bytes * (size_t)j.cfg->height;
     HIP_TRY(hipSetDevice(ctx.hip_device));
+    const double t_job = now_ms();
     const bool in_place = j.sink != Sink::Host && r == 0; /* the root renders straight into the image */
-    const uint64_t my_rows = fr_block_cyclic_rows(j.cfg->height, j.block_rows, r, n);
+    hipEvent_t tc0 = nullptr, tc1 = nullptr; /* around this device's transfers on its copy stream (the last two timing events) */
+    bool tc_started = false;
+    uint64_t bytes_moved = 0;
+    /* every device's launches, step by step: step s renders chunk s of this device and moves chunk s of every peer */
+    std::vector<std::vector<Chunk>> all(n);
+    size_t nsteps = 0;
+    for (uint32_t d = 0; d < n; d++) {
+        all[d] = rank_chunks(d, n, j.nblocks, j.root_share);
+        nsteps = std::max(nsteps, all[d].size());
+    }
+    const std::vector<Chunk> &chunks = all[r];
+    uint64_t my_rows = 0;
+    for (const Chunk &ch : chunks)
+        for (uint32_t k = 0; k < ch.count; k++) {
+            uint32_t y0, y1;
+            block_range(j, ch.first + k * ch.stride, y0, y1);
+            my_rows += y1 - y0;
+        }
     int rc = FR_OK;
     if (!in_place) {
         rc = ctx.reserve(ctx.rgb, my_rows * row_bytes);
         if (rc != FR_OK) return rc;
     }
     uint8_t *scratch = static_cast<uint8_t *>(ctx.rgb.ptr);
-    const uint32_t nb_max = (j.nblocks + n - 1) / n; /* local blocks of device 0, the one with the most */
-    const auto chunks = chunk_schedule(nb_max);
     Rccl &rc_lib = j.set->rccl;
+    if (w.timing_event(2 * nsteps, &tc0) != FR_OK || w.timing_event(2 * nsteps + 1, &tc1) != FR_OK) return FR_ERR_HIP;
+    auto transfers_begin = [&] { /* first transfer of the job: stamp the copy stream where it becomes ready to start */
+        if (!tc_started && hipEventRecord(tc0, ctx.copy_stream) == hipSuccess) tc_started = true;
+    };
     ncclComm_t comm = j.sink == Sink::Rccl ? rc_lib.comms[r] : nullptr;
     size_t local_off = 0, nkernels = 0;
     bool plain_copies = false;
@@ -353,7 +411,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     }
     /* Every exit from this loop falls through to the drain below (kernels and DMAs of earlier chunks may be in
      * flight on three streams into memory the caller frees when we return): no `return` in here. */
-    for (size_t c = 0; c < chunks.size() && rc == FR_OK; c++) {
+    for (size_t c = 0; c < nsteps && rc == FR_OK; c++) {
         if (j.abort->load(std::memory_order_acquire)) {
             rc = fail(FR_ERR_HIP, kEchoError);
             break;
@@ -363,15 +421,8 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             rc = fail(FR_ERR_HIP, "injected failure (fr_debug_inject_multi_failure)");
             break;
         }
-        const uint32_t j0 = chunks[c].first, j1 = chunks[c].second;
-        uint32_t first = 0, count = 0;
-        for (uint32_t k = j0; k < j1; k++) {
-            const uint64_t b = (uint64_t)k * n + r;
-            if (b < j.nblocks) {
-                if (!count) first = (uint32_t)b;
-                count++;
-            }
-        }
+        const Chunk mine = c < chunks.size() ? chunks[c] : Chunk{0, 1, 0};
+        const uint32_t first = mine.first, count = mine.count, stride = mine.stride;
         hipStream_t stream = (c & 1) ? ctx.stream2 : ctx.stream;
         hipEvent_t done = nullptr;
         size_t chunk_off = local_off;
@@ -383,10 +434,10 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             HIP_BRK(hipEventRecord(t0, stream));
             uint64_t rows = 0;
             if (in_place)
-                rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, n, count, 1, j.dst, j.dst_len,
+                rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, stride, count, 1, j.dst, j.dst_len,
                                          stream, &rows);
             else
-                rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, n, count, 0,
+                rc = render_block_cyclic(ctx, j.cfg, j.precision, j.opts, j.block_rows, first, stride, count, 0,
                                          scratch + local_off, (size_t)(my_rows * row_bytes - local_off), stream, &rows);
             if (rc != FR_OK) break;
             HIP_BRK(hipEventRecord(t1, stream));
@@ -402,28 +453,32 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             if (r == 0) {
                 /* the root posts the receives of every peer's chunk c, per peer in the peer's sending order,
                  * straight into the blocks' final places (they do not depend on the root's own kernels) */
+                transfers_begin();
                 rc = rc_lib.check(rc_lib.GroupStart(), "ncclGroupStart");
-                for (uint32_t src = 1; src < n && rc == FR_OK; src++)
-                    for (uint32_t k = j0; k < j1 && rc == FR_OK; k++) {
-                        const uint64_t b = (uint64_t)k * n + src;
-                        if (b >= j.nblocks) continue;
+                for (uint32_t src = 1; src < n && rc == FR_OK; src++) {
+                    if (c >= all[src].size()) continue;
+                    const Chunk &pc = all[src][c];
+                    for (uint32_t k = 0; k < pc.count && rc == FR_OK; k++) {
                         uint32_t y0, y1;
-                        block_range(j, (uint32_t)b, y0, y1);
+                        block_range(j, pc.first + k * pc.stride, y0, y1);
                         rc = rc_lib.check(rc_lib.Recv(j.dst + row_bytes * y0, row_bytes * (y1 - y0), kNcclUint8, (int)src, comm,
                                                       ctx.copy_stream), "ncclRecv");
                     }
+                }
                 int rc2 = rc_lib.check(rc_lib.GroupEnd(), "ncclGroupEnd");
                 if (rc == FR_OK) rc = rc2;
             } else if (count) {
                 HIP_BRK(hipStreamWaitEvent(ctx.copy_stream, done, 0));
+                transfers_begin();
                 rc = rc_lib.check(rc_lib.GroupStart(), "ncclGroupStart");
                 size_t off = chunk_off;
                 for (uint32_t k = 0; k < count && rc == FR_OK; k++) {
                     uint32_t y0, y1;
-                    block_range(j, first + k * n, y0, y1);
+                    block_range(j, first + k * stride, y0, y1);
                     const size_t bytes = row_bytes * (y1 - y0);
                     rc = rc_lib.check(rc_lib.Send(scratch + off, bytes, kNcclUint8, 0, comm, ctx.copy_stream), "ncclSend");
                     off += bytes;
+                    bytes_moved += bytes;
                 }
                 int rc2 = rc_lib.check(rc_lib.GroupEnd(), "ncclGroupEnd");
                 if (rc == FR_OK) rc = rc2;
@@ -432,11 +487,13 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
         }
         if (!count || in_place) continue;
         HIP_BRK(hipStreamWaitEvent(ctx.copy_stream, done, 0));
+        transfers_begin();
         size_t off = chunk_off;
         for (uint32_t k = 0; k < count && rc == FR_OK; k++) {
             uint32_t y0, y1;
-            block_range(j, first + k * n, y0, y1);
+            block_range(j, first + k * stride, y0, y1);
             const size_t bytes = row_bytes * (y1 - y0), dst_off = row_bytes * y0;
+            bytes_moved += bytes;
             if (j.sink == Sink::PeerCopy) {
                 if (ctx.hip_device == j.root_device) {
                     HIP_BRK(hipMemcpyAsync(j.dst + dst_off, scratch + off, bytes, hipMemcpyDeviceToDevice, ctx.copy_stream));
@@ -495,6 +552,7 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
+    const bool tc_ended = tc_started && hipEventRecord(tc1, ctx.copy_stream) == hipSuccess;
     /* drain, error or not */
     hipError_t e1 = hipStreamSynchronize(ctx.stream);
     hipError_t e2 = hipStreamSynchronize(ctx.stream2);
@@ -514,6 +572,14 @@ int device_job(Worker &w, const Job &j, fr_multi_stats *stats) {
     stats->kernels[r] = (uint32_t)nkernels;
     stats->kernel_ms[r] = total;
     stats->rows[r] = my_rows;
+    float span = 0.0f;
+    if (tc_ended && hipEventElapsedTime(&span, tc0, tc1) != hipSuccess) {
+        (void)hipGetLastError();
+        span = 0.0f;
+    }
+    stats->transfer_span_ms[r] = span;
+    stats->bytes_moved[r] = bytes_moved;
+    stats->job_ms[r] = now_ms() - t_job;
     return FR_OK;
 }
 
@@ -574,7 +640,7 @@ int run_multi(const fr_config *cfg, int precision, uint32_t block_rows, Sink sin
     std::unique_ptr<PinProgress> pins;
     if (sink == Sink::Host) pins.reset(new PinProgress(dst, need));
     Job job{cfg, precision, default_opts(), block_rows, (uint32_t)(((uint64_t)cfg->height + block_rows - 1) / block_rows), n, sink,
-            dst, dst_len, set->devices[0], pins.get(), set, &abort};
+            dst, dst_len, set->devices[0], pins.get(), set, &abort, g_root_share.load()};
     /* which kernel suits the view: decided once for the whole image (on the first device), not by every chunk launch */
     if (hipSetDevice(set->devices[0]) == hipSuccess) decide_kernel(set->workers[0]->ctx, cfg, precision, 0, cfg->height, job.opts, nullptr, false);
     (void)hipGetLastError();
@@ -694,6 +760,12 @@ int fr_init_devices(const int *devices, int n) {
         multi_shutdown_locked();
         return fail(rc, err);
     }
+    return FR_OK;
+}
+
+int fr_set_multi_root_share(int q) {
+    if (q != 0 && q != 1 && q != 2 && q != 4) return fail(FR_ERR_INVALID_ARGUMENT, "root share must be 1 (all of its blocks), 2, 4 (a half, a quarter) or 0 (none)");
+    g_root_share.store(q);
     return FR_OK;
 }
 

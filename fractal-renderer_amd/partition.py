@@ -56,19 +56,61 @@ def num_blocks(height, block_rows):
     return (height + block_rows - 1) // block_rows
 
 
+def shares(rank, world, root_share=1):
+    """The row blocks of rank `rank` as arithmetic progressions (first_block, stride) — what one launch of the C ABI's
+    block-cyclic entry points renders.  root_share = 1 (default): plain cyclic dealing, block b -> rank b % world.
+    root_share = q in {2, 4}: the sink (rank 0) keeps only every q-th of ITS blocks — a 1/q share — and the rest of them are
+    dealt round-robin to the other ranks, each of which then holds its own progression plus q - 1 short ones;
+    root_share = 0: the sink renders nothing and only receives.  (Whether the sink should render less is a question for the
+    first real multi-GPU run — DESIGN.md §4; the bytes are the same whatever the dealing.)"""
+    q = int(root_share)
+    if q not in (0, 1, 2, 4):
+        raise ValueError("root_share must be 1 (full share), 2, 4 (a half, a quarter) or 0 (the sink only receives)")
+    if world == 1 or q == 1:
+        return [(rank, world)]
+    peers = world - 1
+    if rank == 0:
+        return [] if q == 0 else [(0, q * world)]
+    out = [(rank, world)]
+    if q == 0:  # every block of the sink: block j * world, j = 0, 1, ... -> peer 1 + j % peers
+        out.append(((rank - 1) * world, peers * world))
+    else:       # the sink's blocks j * world with j % q == c, c = 1 .. q - 1: the i-th of them -> peer 1 + i % peers
+        for c in range(1, q):
+            out.append(((c + q * (rank - 1)) * world, q * peers * world))
+    return out
+
+
+def share_blocks(rank, world, nblocks, root_share=1):
+    """Per progression of shares(): the global block indices below nblocks, in rendering order."""
+    return [list(range(first, nblocks, stride)) for first, stride in shares(rank, world, root_share)]
+
+
+def rank_chunks(rank, world, nblocks, root_share=1):
+    """The launches of one rank for one image: a list of chunks, each a list of global block indices forming an arithmetic
+    progression (one call of render_chunk_hip).  Every rank can compute every rank's list: step s of the gather moves
+    chunk s of every peer."""
+    out = []
+    for (first, stride), blocks in zip(shares(rank, world, root_share), share_blocks(rank, world, nblocks, root_share)):
+        # the schedule of the LONGEST progression of this stride (the one starting at block 0), so that ranks whose
+        # progression is one block shorter cut it at the same places
+        for j0, j1 in chunk_schedule((nblocks + stride - 1) // stride):
+            if blocks[j0:j1]:
+                out.append(blocks[j0:j1])
+    return out
+
+
 def block_range(height, block_rows, b):
     """Image rows [y0, y1) of block b."""
     y0 = b * block_rows
     return y0, min(height, y0 + block_rows)
 
 
-def local_rows(height, block_rows, rank, world):
-    """Rows rank `rank` renders (same arithmetic as fr_block_cyclic_rows in the C ABI)."""
+def local_rows(height, block_rows, rank, world, root_share=1):
+    """Rows rank `rank` renders (per progression the arithmetic of fr_block_cyclic_rows in the C ABI)."""
     rows = 0
-    b = rank
-    while b * block_rows < height:
-        rows += min(block_rows, height - b * block_rows)
-        b += world
+    for blocks in share_blocks(rank, world, num_blocks(height, block_rows), root_share):
+        for b in blocks:
+            rows += min(block_rows, height - b * block_rows)
     return rows
 
 
@@ -100,16 +142,21 @@ def render_chunk_hip(config, precision, block_rows, first_block, block_stride, m
     return rows.value
 
 
-def render_local_hip(config, precision, block_rows, rank, world, out, stream_ptr):
-    """Render this rank's whole share, packed, in ONE launch (used when nothing is gathered)."""
-    rows = C.c_uint64(0)
-    _native.check(
-        _native.load().fr_render_block_cyclic_rgb8_device(
-            C.byref(config), int(precision), block_rows, rank, world, out.data_ptr(), out.numel(), stream_ptr,
-            C.byref(rows),
+def render_local_hip(config, precision, block_rows, rank, world, out, stream_ptr, root_share=1):
+    """Render this rank's whole share, packed, in ONE launch per progression (used when nothing is gathered)."""
+    total, off = 0, 0
+    for first, stride in shares(rank, world, root_share):
+        rows = C.c_uint64(0)
+        part = out[off:]
+        _native.check(
+            _native.load().fr_render_block_cyclic_rgb8_device(
+                C.byref(config), int(precision), block_rows, first, stride, part.data_ptr(), part.numel(), stream_ptr,
+                C.byref(rows),
+            )
         )
-    )
-    return rows.value
+        total += rows.value
+        off += rows.value * 3 * config.width
+    return total
 
 
 def assemble(gathered, height, row_bytes, block_rows, world):
@@ -139,8 +186,10 @@ class DistributedRenderer:
     render_rows(config, precision, y0, y1, out_view)."""
 
     def __init__(self, config, precision=0, block_rows=DEFAULT_BLOCK_ROWS, group=None, device=None,
-                 render_rows=None, force_blocks=False):
+                 render_rows=None, force_blocks=False, root_share=1):
         self.config = config
+        self.root_share = int(root_share)
+        self.timing = None  # set to a dict by render(diagnose=True): per-chunk device events of ONE step
         self.precision = int(precision)
         self.block_rows = int(block_rows)
         self.group = group
@@ -157,7 +206,7 @@ class DistributedRenderer:
             device = torch.device("cuda", torch.cuda.current_device()) if self.cuda else torch.device("cpu")
         self.device = device
         self._render_rows = render_rows
-        my = local_rows(self.height, self.block_rows, self.rank, self.world)
+        my = local_rows(self.height, self.block_rows, self.rank, self.world, self.root_share)
         if self.rank == 0:
             self.image = torch.empty(max(self.height * self.row_bytes, 1), dtype=torch.uint8, device=device)
             self.local = None
@@ -186,11 +235,13 @@ class DistributedRenderer:
             self._render_rows(self.config, self.precision, y0, y1, out)
 
     # -- the step -------------------------------------------------------------------------
-    def render(self):
+    def render(self, diagnose=False):
         """One full image.  Returns the [height, width, 3] uint8 image on rank 0, None elsewhere.
         On CUDA the call is asynchronous w.r.t. the host except for torch.distributed's own
         bookkeeping; call torch.cuda.synchronize() (or use the result on the current stream,
-        which is made to wait for the gather) before reading."""
+        which is made to wait for the gather) before reading.
+        diagnose=True (CUDA): device events around every chunk's kernel and every step's transfers are kept in
+        self.timing for step_report() — what bench.py prints per rank for an N > 1 run."""
         cfg, B, N, r = self.config, self.block_rows, self.world, self.rank
         if N == 1 and not self.force_blocks:
             # single launch of the whole image, rendered in place
@@ -199,19 +250,31 @@ class DistributedRenderer:
 
         works = []
         local_off = 0
+        timing = {"kernels": [], "transfers": [], "bytes_sent": 0, "bytes_received": 0, "blocks": 0} if (diagnose and self.cuda) else None
         if self.cuda:
             for st in self.block_streams[1:]:
                 st.wait_stream(self.compute_stream)  # order behind earlier work
-        nb_max = (self.nblocks + N - 1) // N  # local blocks of rank 0, the rank with the most
-        for c, (j0, j1) in enumerate(chunk_schedule(nb_max)):
-            mine = [j * N + r for j in range(j0, j1) if j * N + r < self.nblocks]
+            if timing is not None:
+                timing["t0"] = torch.cuda.Event(enable_timing=True)
+                timing["t0"].record(self.compute_stream)
+        # every rank's launches, step by step: step s renders chunk s of this rank and moves chunk s of every peer
+        chunks = [rank_chunks(q, N, self.nblocks, self.root_share) for q in range(N)]
+        nsteps = max(len(c) for c in chunks)
+        for s in range(nsteps):
+            mine = chunks[r][s] if s < len(chunks[r]) else []
             done_event, sends = None, []
             if mine:
-                stream = self.block_streams[c % N_BLOCK_STREAMS]
+                stream = self.block_streams[s % N_BLOCK_STREAMS]
+                stride = mine[1] - mine[0] if len(mine) > 1 else 1
+                if timing is not None:
+                    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    k0.record(stream)
+                    timing["kernels"].append((k0, k1))
+                    timing["blocks"] += len(mine)
                 if r == 0:
                     # rank 0 renders every chunk in place
                     if self.cuda:
-                        render_chunk_hip(cfg, self.precision, B, mine[0], N, len(mine), True, self.image,
+                        render_chunk_hip(cfg, self.precision, B, mine[0], stride, len(mine), True, self.image,
                                          stream.cuda_stream)
                     else:
                         for b in mine:
@@ -221,7 +284,7 @@ class DistributedRenderer:
                     rows = sum(block_range(self.height, B, b)[1] - block_range(self.height, B, b)[0] for b in mine)
                     chunk = self.local[local_off : local_off + rows * self.row_bytes]
                     if self.cuda:
-                        render_chunk_hip(cfg, self.precision, B, mine[0], N, len(mine), False, chunk, stream.cuda_stream)
+                        render_chunk_hip(cfg, self.precision, B, mine[0], stride, len(mine), False, chunk, stream.cuda_stream)
                     off = 0
                     for b in mine:
                         y0, y1 = block_range(self.height, B, b)
@@ -232,11 +295,13 @@ class DistributedRenderer:
                         off += (y1 - y0) * self.row_bytes
                     local_off += rows * self.row_bytes
                 if self.cuda:
+                    if timing is not None:
+                        timing["kernels"][-1][1].record(stream)
                     done_event = torch.cuda.Event()
                     done_event.record(stream)
             if N == 1:
                 continue
-            # hand chunk c to the communication stream; chunk c+1 renders meanwhile
+            # hand step s to the communication stream; the next chunk renders meanwhile
             if self.cuda:
                 if done_event is not None and r != 0:
                     self.comm_stream.wait_event(done_event)  # a send needs its chunk; rank 0's receives do not
@@ -247,15 +312,23 @@ class DistributedRenderer:
                 if r == 0:
                     ops = []
                     for src in range(1, N):  # per peer, in the peer's own sending order
-                        for j in range(j0, j1):
-                            b = j * N + src
-                            if b < self.nblocks:
-                                y0, y1 = block_range(self.height, B, b)
-                                ops.append(dist.P2POp(dist.irecv, self._image_rows(y0, y1), src, self.group))
+                        for b in (chunks[src][s] if s < len(chunks[src]) else []):
+                            y0, y1 = block_range(self.height, B, b)
+                            ops.append(dist.P2POp(dist.irecv, self._image_rows(y0, y1), src, self.group))
+                            if timing is not None:
+                                timing["bytes_received"] += (y1 - y0) * self.row_bytes
                 else:
                     ops = [dist.P2POp(dist.isend, part, 0, self.group) for part in sends]
+                    if timing is not None:
+                        timing["bytes_sent"] += sum(p.numel() for p in sends)
                 if ops:
+                    if timing is not None:
+                        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        c0.record(self.comm_stream)
                     works.extend(dist.batch_isend_irecv(ops))
+                    if timing is not None:
+                        c1.record(self.comm_stream)
+                        timing["transfers"].append((c0, c1))
         for w in works:
             w.wait()  # CUDA: makes the current stream wait for the transfer; gloo: blocks
         if self.cuda:
@@ -263,9 +336,36 @@ class DistributedRenderer:
                 self.compute_stream.wait_stream(st)
             if self.comm_stream is not None:
                 self.compute_stream.wait_stream(self.comm_stream)
+            if timing is not None:
+                timing["t1"] = torch.cuda.Event(enable_timing=True)
+                timing["t1"].record(self.compute_stream)
+                self.timing = timing
         if r == 0:
             return self.image[: self.height * self.row_bytes].view(self.height, cfg.width, 3)
         return None
+
+    def step_report(self):
+        """After render(diagnose=True) and a device synchronisation: this rank's step in milliseconds of DEVICE time —
+        kernel_ms (its chunk kernels, summed), compute_span_ms (first kernel start to last kernel end), transfer_ms (its
+        grouped P2P calls on the communication stream, summed: sends on a peer, receives on the sink), transfer_span_ms,
+        step_ms (start of the step to everything joined on the compute stream), idle_ms = step - compute span, and the
+        bytes it sent / received.  bench.py gathers these from every rank."""
+        t = self.timing
+        if not t:
+            return None
+
+        def span(pairs):
+            if not pairs:
+                return 0.0, 0.0
+            total = sum(a.elapsed_time(b) for a, b in pairs)
+            return total, max(t["t0"].elapsed_time(b) for _, b in pairs) - min(t["t0"].elapsed_time(a) for a, _ in pairs)
+
+        k_sum, k_span = span(t["kernels"])
+        c_sum, c_span = span(t["transfers"])
+        step = t["t0"].elapsed_time(t["t1"])
+        return {"rank": self.rank, "blocks": t["blocks"], "launches": len(t["kernels"]), "kernel_ms": k_sum, "compute_span_ms": k_span,
+                "transfer_ms": c_sum, "transfer_span_ms": c_span, "step_ms": step, "idle_ms": max(step - k_span, 0.0),
+                "bytes_sent": t["bytes_sent"], "bytes_received": t["bytes_received"]}
 
 
 class _NullContext:
@@ -277,6 +377,6 @@ class _NullContext:
 
 
 def render_distributed(config, precision=0, block_rows=DEFAULT_BLOCK_ROWS, group=None, render_rows=None,
-                       device=None):
+                       device=None, root_share=1):
     """One-shot convenience wrapper around DistributedRenderer."""
-    return DistributedRenderer(config, precision, block_rows, group, device, render_rows).render()
+    return DistributedRenderer(config, precision, block_rows, group, device, render_rows, root_share=root_share).render()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 2
+#define FR_ABI_VERSION 3
 
 typedef enum fr_status {
     FR_OK = 0,
@@ -219,6 +219,12 @@ typedef enum fr_gather { FR_GATHER_PEER_COPY = 0, FR_GATHER_RCCL = 1 } fr_gather
 int fr_render_rgb8_multi_device(const fr_config *cfg, int precision, uint32_t block_rows, int gather, void *d_out,
                                 size_t out_len);
 
+/* Who renders the sink's row blocks.  The set's first device is both a renderer and the sink of the gather; by default it
+ * renders all of its blocks (plain cyclic dealing, q = 1).  q = 2 / 4: it keeps every 2nd / 4th of them and the rest are dealt
+ * round-robin to the other devices; q = 0: it renders nothing and only receives.  Same bytes; a tuning knob for the first
+ * real multi-GPU run (bench.py --root-share, which prints where every device's time went).  Process-wide. */
+int fr_set_multi_root_share(int q);
+
 /* Timing of the calling thread's last multi-device render: per device, the time its render kernels
  * took (HIP events, summed over its chunks) and the host-side wall time of the whole call. */
 #define FR_MAX_DEVICES 16
@@ -228,6 +234,11 @@ typedef struct fr_multi_stats {
     float kernel_ms[FR_MAX_DEVICES];    /* their summed duration */
     uint64_t rows[FR_MAX_DEVICES];      /* rows each device rendered */
     double wall_ms;                     /* the call, entry to return */
+    /* ABI 3: where each device's time went, for the first real multi-GPU run to be read against DESIGN.md 4's prediction */
+    float transfer_span_ms[FR_MAX_DEVICES]; /* device time from its first transfer (DMA / ncclSend; the sink: ncclRecv) being
+                                             * ready to start to its last one done; 0 for a device that moves nothing */
+    double job_ms[FR_MAX_DEVICES];          /* host wall time of the device's whole job: first launch to streams drained */
+    uint64_t bytes_moved[FR_MAX_DEVICES];   /* bytes the device sent to the sink (host buffer or first device's HBM) */
 } fr_multi_stats;
 int fr_multi_last_stats(fr_multi_stats *stats);
 

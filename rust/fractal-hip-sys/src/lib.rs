@@ -50,7 +50,7 @@ pub struct fr_config {
 
 pub const FR_OK: c_int = 0;
 /// `FR_ABI_VERSION` of the header these declarations were written against; `check_abi()` compares it with the library's.
-pub const FR_ABI_VERSION: c_int = 2;
+pub const FR_ABI_VERSION: c_int = 3;
 pub const FR_PRECISION_F64: c_int = 0;
 pub const FR_PRECISION_F32: c_int = 1;
 

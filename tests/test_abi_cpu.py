@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(fr):
     for s in syms:
         assert hasattr(lib, s), "libfractal_hip.so does not export %s" % s
     assert set(syms) == set(_native.PROTOTYPES), "python prototypes out of sync with the header"
-    assert lib.fr_abi_version() == 2
+    assert lib.fr_abi_version() == 3
     assert len(lib.fr_build_id()) == 16
 
 

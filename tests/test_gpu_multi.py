@@ -389,6 +389,38 @@ def test_multi_device_failure_rccl_sink_needs_two_gpus(fr, lib):
     fr.init_devices([0])
 
 
+@pytest.mark.parametrize("q", [2, 4, 0])
+def test_the_sink_device_may_render_a_smaller_share(fr, lib, q):
+    """fr_set_multi_root_share — the first device keeps a half / a quarter / none of its row blocks, the others
+    take them over as extra arithmetic progressions (the dealing of partition.py: shares).  Three and five logical devices,
+    host sink and peer gather, ragged and C2-shaped images: the bytes are those of the single render."""
+    import torch
+
+    from fractal_renderer_amd import _native
+
+    try:
+        _native.check(lib.fr_set_multi_root_share(q))
+        for devices in ([0, 0, 0], [0] * 5):
+            fr.init_devices(devices)
+            for width, height, block_rows, iters in ((1237, 1001, 8, 150), (2048, 4096, 64, 200), (513, 77, 8, 64)):
+                cfg, _ = cfg_of(fr, width, height, iters)
+                want = fr.get_image(cfg)
+                got = fr.get_image_multi(cfg, 0, block_rows)
+                assert np.array_equal(got, want), (q, devices, width, height, "host sink")
+                st = fr.multi_stats()
+                assert sum(st["rows"]) == height
+                if q == 0:
+                    assert st["rows"][0] == 0 and st["kernels"][0] == 0
+                d = torch.zeros(want.nbytes, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                _native.check(lib.fr_render_rgb8_multi_device(C.byref(cfg), 0, block_rows, 0, C.c_void_p(d.data_ptr()), d.numel()))
+                assert np.array_equal(d.cpu().numpy().reshape(want.shape), want), (q, devices, width, height, "peer gather")
+        assert lib.fr_set_multi_root_share(3) == _native.FR_ERR_INVALID_ARGUMENT
+    finally:
+        _native.check(lib.fr_set_multi_root_share(1))
+        fr.init_devices([0])
+
+
 def test_multi_host_buffer_pinned_by_the_caller(fr, lib):
     """fr_pin_host_buffer: a frame buffer that is rendered into again and again is pinned once by its owner; the
     multi-device and the single-device host renders find it registered and produce the same bytes."""

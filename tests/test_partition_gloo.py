@@ -31,7 +31,7 @@ def _oracle_render_rows(ocfg):
     return render
 
 
-def _worker(rank, world, port, w, h, block_rows, q):
+def _worker(rank, world, port, w, h, block_rows, q, root_share=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,7 +43,7 @@ def _worker(rank, world, port, w, h, block_rows, q):
 
         ocfg = O.cli_config(w, h, iterations=60)
         cfg = fr.Config.from_buffer_copy(bytes(ocfg))
-        renderer = P.DistributedRenderer(cfg, 0, block_rows, render_rows=_oracle_render_rows(ocfg))
+        renderer = P.DistributedRenderer(cfg, 0, block_rows, render_rows=_oracle_render_rows(ocfg), root_share=root_share)
         ok = True
         for _ in range(2):  # buffers are reused across steps
             img = renderer.render()
@@ -67,6 +67,46 @@ def test_block_cyclic_gather_reassembles_the_image(world, w, h, block_rows):
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world,w,h,block_rows,root_share", [(2, 16, 70, 8, 2), (3, 20, 101, 4, 4), (4, 12, 203, 8, 0), (8, 10, 1003, 8, 2),
+                                                              (3, 9, 5, 8, 0)])
+def test_the_sink_may_render_a_smaller_share(world, w, h, block_rows, root_share):
+    """rank 0 is both a renderer and the sink of the gather; root_share deals part (1/2, 1/4) or all (0) of
+    ITS blocks to the other ranks — each then holds several arithmetic progressions of blocks, every chunk still one launch
+    of the C ABI — and the image must come out the same."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, block_rows, q, root_share)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
+
+
+def test_every_dealing_covers_every_block_exactly_once_in_progressions():
+    from fractal_renderer_amd import partition as P
+
+    for world in (1, 2, 3, 4, 8, 16):
+        for q in (1, 2, 4, 0):
+            for nb in (1, 7, 13, 64, 256):
+                owner = {}
+                for r in range(world):
+                    for ch in P.rank_chunks(r, world, nb, q):
+                        assert ch and all(ch[i + 1] - ch[i] == ch[1] - ch[0] for i in range(len(ch) - 1))  # one launch each
+                        for b in ch:
+                            assert b not in owner and 0 <= b < nb
+                            owner[b] = r
+                assert sorted(owner) == list(range(nb)), (world, q, nb)
+                if world > 1 and q == 0:
+                    assert 0 not in owner.values()
+                if world > 1 and q in (2, 4) and nb >= 4 * world * q:
+                    mine = sum(1 for v in owner.values() if v == 0)
+                    assert abs(mine - nb / (world * q)) <= 1, (world, q, nb, mine)
+    # plain cyclic dealing is what it always was: block b -> rank b % world, the same cuts for every rank
+    assert P.rank_chunks(1, 8, 64, 1) == [[1], [9, 17], [25, 33], [41, 49], [57]]
+    assert P.rank_chunks(7, 8, 63, 1) == [[7], [15, 23], [31, 39], [47, 55]]
 
 
 def test_partition_arithmetic_matches_the_c_abi():
