@@ -241,3 +241,46 @@ def test_reference_screenshot_agrees_with_the_oracles_channel_order_and_inside_r
     meas = (~inside) & (R >= 16) & (B < 250)
     ratio = B[meas] / R[meas]
     assert meas.sum() > 100 and abs(np.median(ratio) - want_ratio) / want_ratio < 0.03
+
+
+def test_geometry_against_the_reference_s_own_screenshot():
+    """the one output the reference holds, screenshots/mandelbrot-1000000x.avif, is examples.md:29's view
+    (-s 500000 -x -.7436447860 -y .1318252536 -i 4000 -d) rendered square — found by searching scale x iterations with the
+    oracle (tests/golden/make_screenshot_geometry.py, which committed the screenshot's BLACK MASK at 125 x 125 cells and the
+    search table, not the image).  The oracle's interior mask must overlap it in the reference's orientation and in no
+    other: that pins `x / height`, y-down, the centre convention and the meaning of --scale (calc/src/lib.rs:182-197) against
+    something the REFERENCE produced.  (A lossy, rescaled image pins no bits: parity stays 'unpinned' in the task's sense.)"""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_screenshot_geometry.json")
+    doc = json.load(open(path))
+    n = doc["mask_cells"]
+    ref = np.array([[c == "1" for c in bin(int(row, 16))[2:].zfill(n)] for row in doc["mask_rows_hex"]])
+    assert ref.shape == (n, n) and abs(ref.mean() - doc["black_fraction_screenshot"]) < 0.01
+    v = doc["view"]
+    assert (v["scale"], v["iterations"], v["inside"]) == (500000.0, 4000, 0)  # examples.md:29
+    cfg = O.cli_config(500, 500, O.MANDELBROT, iterations=v["iterations"], scale=(v["scale"], v["scale"]),
+                       pos=(float.fromhex(v["pos"][0]), float.fromhex(v["pos"][1])), inside=0)
+    _, iters = O.escape_rows(cfg)
+    black = iters >= cfg.iterations  # what `inside = false` paints BLACK (calc/src/lib.rs:233)
+    # ... and the colour path agrees: those pixels (bar the bounded orbits that end with |z|^2 > stable_limit, which are
+    # coloured as outside: KAT-3), and only those (bar a few dim exterior ones), come out (0, 0, 0)
+    img = O.get_image(cfg)
+    assert (img[black].max(axis=1) == 0).mean() > 0.97 and (img[~black].max(axis=1) > 0).mean() > 0.99
+    m = black.reshape(n, 4, n, 4).mean(axis=(1, 3)) >= 0.5
+
+    def iou(a, b):
+        return (a & b).sum() / max((a | b).sum(), 1)
+
+    got = {"identity": iou(m, ref), "flip_y": iou(m[::-1], ref), "flip_x": iou(m[:, ::-1], ref), "transpose": iou(m.T, ref),
+           "rot180": iou(m[::-1, ::-1], ref)}
+    assert got["identity"] > 0.93, got
+    assert max(got["flip_y"], got["flip_x"], got["transpose"], got["rot180"]) < 0.6, got
+    # the committed search: this view is the best of the grid, and brightness fits best near exposure / iterations ~ 1 / 1500
+    best = max(doc["iou_search"], key=lambda r: r["identity"])
+    assert (best["scale"], best["iterations"]) == (500000.0, 4000) and best["identity"] > 0.97
+    assert all(r["identity"] < 0.8 for r in doc["iou_search"] if r["scale"] != 500000.0)
+    fit = max(doc["colour_fit"], key=lambda r: r["identity"]["psnr_db"])
+    assert fit["identity"]["psnr_db"] > 20 and fit["identity"]["corr_blue"] > 0.9
+    assert all(fit[k]["psnr_db"] < fit["identity"]["psnr_db"] - 5 for k in ("flip_y", "flip_x", "transpose"))
