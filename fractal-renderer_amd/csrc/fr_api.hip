@@ -507,6 +507,11 @@ void fill_params(const fr_config *cfg, const Opts &o, fr_kparams &p) {
         if (dbg_want > 0 && dbg_want <= 64) p.queue_want = (uint32_t)dbg_want;
         if (dbg_minrun >= 0) p.queue_minrun = (uint32_t)dbg_minrun;
     }
+    {
+        /* measurement aid (WRONG IMAGES; DESIGN.md 7, tools/c4_ablation.sh): what the hand-over's stores and the second pass cost */
+        static const int dbg_ablate = getenv("FR_DEBUG_ABLATE") ? atoi(getenv("FR_DEBUG_ABLATE")) : 0;
+        p.debug_ablate = (uint32_t)dbg_ablate & 3u;
+    }
     /* the flag bit of the loop's return value needs iterations < 2^31; keep a margin */
     p.cycle_shortcut = (o.cycle_shortcut && cfg->iterations < (1u << 30)) ? 1u : 0u;
     /* the colour filter's constants (fr_kernels.hip: colour_outside_filtered) and the conditions under

@@ -387,7 +387,11 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
         rc = ctx.event(2 * b, &ek);
         if (rc == FR_OK) rc = ctx.event(2 * b + 1, &ec);
         if (rc != FR_OK) break;
-        if ((err = hipEventRecord(ek, st)) != hipSuccess) what = "hipEventRecord";
+        if (nb == 1) {
+            /* a small frame: nothing to overlap the copy with — behind its kernel on the same stream, no cross-stream hop */
+            if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, st)) != hipSuccess) what = "hipMemcpyAsync";
+            else if ((err = hipEventRecord(ec, st)) != hipSuccess) what = "hipEventRecord";
+        } else if ((err = hipEventRecord(ek, st)) != hipSuccess) what = "hipEventRecord";
         else if ((err = hipStreamWaitEvent(ctx.copy_stream, ek, 0)) != hipSuccess) what = "hipStreamWaitEvent";
         else if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, ctx.copy_stream)) != hipSuccess) what = "hipMemcpyAsync";
         else if ((err = hipEventRecord(ec, ctx.copy_stream)) != hipSuccess) what = "hipEventRecord";

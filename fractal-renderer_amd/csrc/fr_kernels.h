@@ -90,6 +90,8 @@ struct fr_kparams {
                               * 28 tiles differ too much in cost to balance) */
     uint32_t strip_tiles; /* strip length asked for by the caller: first pass 4 (GUI-sized launches) else 7; strip kernel
                            * (tile 0, RGB) 1 / 2 / 4 / 7, 0 = by launch size */
+    uint32_t debug_ablate;  /* measurement aid, never set by the product path (FR_DEBUG_ABLATE; WRONG IMAGES): bit 0 = the first pass
+                             * claims its list slots but does not store the entries, bit 1 = the second pass is not launched */
     uint32_t surv_sub_capacity;
     void *surv_z;           /* T[2] per entry: the position after first_cap iterations */
     uint32_t *surv_pos;     /* uint32[2] per entry: output column, output row */

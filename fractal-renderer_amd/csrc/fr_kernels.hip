@@ -1767,7 +1767,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                         base = __builtin_amdgcn_readfirstlane(base);
                         const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
                         const bool mine = lane_in(run) && slot < sub_cap; /* a full list is not an error: those lanes finish here */
-                        if (mine) {
+                        if (mine && !(kp->debug_ablate & 1u)) {
                             const size_t e = (size_t)list * sub_cap + slot;
                             T2 zz;
                             zz.x = X * (T)0.5, zz.y = Y * (T)0.5; /* exact */
@@ -3142,6 +3142,7 @@ hipError_t launch_two_pass(const fr_kparams &p, const fr_kout &out, hipStream_t 
                                                            : launch_first_pass<T, 7>(p, out, stream, v1);
     if (e != hipSuccess) return e;
     if (p.first_only) return hipSuccess; /* nothing was handed over: there are no lists */
+    if (p.debug_ablate & 2u) return hipSuccess; /* measurement aid: the first pass's cost on its own */
     if (p.loop_mode == 4) return launch_queue_form<T, 4, 1>(p, out, stream);
     return launch_queue_form<T, 2, 1>(p, out, stream);
 }
