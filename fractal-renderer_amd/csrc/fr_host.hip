@@ -348,7 +348,8 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     const bool trace = trace_enabled();
     const double t_start = now_ms();
 
-    /* bands: ~6 MiB each, at most four (a 3840 x 2160 RGB frame: four of 6.2 MB; 1920 x 1080: two; 750 x 500: one) */
+    /* bands: ~6 MiB each, at most four (a 3840 x 2160 RGB frame: four of 6.2 MB; 1920 x 1080: two; 750 x 500: one).  Few and
+     * large: at these sizes the host's HIP calls (5-10 us each) are a visible share of the frame, and every band costs three */
     const uint32_t rows = y1 - y0;
     uint32_t nb = (uint32_t)((need + ((size_t)6 << 20) - 1) / ((size_t)6 << 20));
     if (need >= ((size_t)3 << 20) && nb < 2) nb = 2;
@@ -383,18 +384,13 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
         last = st;
         rc = render_on(st, ya, yb, scratch + a);
         if (rc != FR_OK) break;
-        hipEvent_t ek, ec;
-        rc = ctx.event(2 * b, &ek);
-        if (rc == FR_OK) rc = ctx.event(2 * b + 1, &ec);
+        hipEvent_t ec;
+        rc = ctx.event(b, &ec);
         if (rc != FR_OK) break;
-        if (nb == 1) {
-            /* a small frame: nothing to overlap the copy with — behind its kernel on the same stream, no cross-stream hop */
-            if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, st)) != hipSuccess) what = "hipMemcpyAsync";
-            else if ((err = hipEventRecord(ec, st)) != hipSuccess) what = "hipEventRecord";
-        } else if ((err = hipEventRecord(ek, st)) != hipSuccess) what = "hipEventRecord";
-        else if ((err = hipStreamWaitEvent(ctx.copy_stream, ek, 0)) != hipSuccess) what = "hipStreamWaitEvent";
-        else if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, ctx.copy_stream)) != hipSuccess) what = "hipMemcpyAsync";
-        else if ((err = hipEventRecord(ec, ctx.copy_stream)) != hipSuccess) what = "hipEventRecord";
+        /* the band's DMA behind its kernel on the SAME stream (no cross-stream event: two HIP calls fewer per band); bands
+         * alternate between two streams, so band b + 1 renders while band b travels */
+        if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, st)) != hipSuccess) what = "hipMemcpyAsync";
+        else if ((err = hipEventRecord(ec, st)) != hipSuccess) what = "hipEventRecord";
     }
     ctx.post_sample(pending_sample, last); /* a first frame of the view: its statistics, behind the last band */
     const double t_enqueued = now_ms();
@@ -404,6 +400,7 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     const int helpers = need >= ((size_t)3 << 20) ? copy_helpers() : 0;
     if (helpers > 0 && !ctx.copy_pool) ctx.copy_pool = new CopyPool(helpers);
     CopyPool *pool = helpers > 0 ? ctx.copy_pool : nullptr;
+
     auto spread = [&](uint8_t *dst, const uint8_t *src, size_t len, int kind) {
         if (!pool || len < ((size_t)1 << 20)) {
             CopyPool::run(CopyPool::Piece{dst, src, len, kind});
@@ -424,7 +421,7 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
         const uint32_t ya = y0 + b * band_rows, yb = ya + band_rows < y1 ? ya + band_rows : y1;
         const size_t a = row_bytes * (size_t)(ya - y0), len = row_bytes * (size_t)(yb - ya);
         hipEvent_t ec;
-        rc = ctx.event(2 * b + 1, &ec);
+        rc = ctx.event(b, &ec);
         if (rc != FR_OK) break;
         if ((err = wait_event(ec)) != hipSuccess) {
             what = "waiting for a band's DMA";
