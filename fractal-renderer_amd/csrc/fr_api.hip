@@ -189,13 +189,25 @@ int Ctx::create(int device) {
 int Ctx::reserve_stage(size_t bytes) {
     if (bytes <= stage_cap) return FR_OK;
     if (stage) (void)hipHostFree(stage);
-    stage = nullptr, stage_cap = 0;
-    const hipError_t e = hipHostMalloc(&stage, bytes, hipHostMallocDefault);
+    stage = stage_dev = nullptr, stage_cap = 0;
+    hipError_t e = hipHostMalloc(&stage, bytes, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&stage_dev, stage, 0);
+    if (e == hipSuccess && !stage_flags) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&stage_flags), 8 * sizeof(unsigned long long), hipHostMallocMapped);
+        if (e == hipSuccess) {
+            memset(stage_flags, 0, 8 * sizeof(unsigned long long));
+            e = hipHostGetDevicePointer(reinterpret_cast<void **>(&stage_flags_dev), stage_flags, 0);
+        }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&stage_counters), 8 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(stage_counters, 0, 8 * sizeof(unsigned int));
+    }
     if (e != hipSuccess) {
-        stage = nullptr;
-        return fail_hip(e, "hipHostMalloc(staging buffer)");
+        if (stage) (void)hipHostFree(stage);
+        stage = stage_dev = nullptr;
+        return fail_hip(e, "staging buffer (hipHostMalloc)");
     }
     stage_cap = bytes;
+    memset(stage, 0, bytes); /* every page exists before the first frame */
     return FR_OK;
 }
 
@@ -227,7 +239,10 @@ void Ctx::destroy() {
     if (copy_pool) destroy_copy_pool(copy_pool);
     copy_pool = nullptr;
     if (stage) (void)hipHostFree(stage);
-    stage = nullptr, stage_cap = 0;
+    stage = stage_dev = nullptr, stage_cap = 0;
+    if (stage_flags) (void)hipHostFree(stage_flags);
+    if (stage_counters) (void)hipFree(stage_counters);
+    stage_flags = stage_flags_dev = nullptr, stage_counters = nullptr;
     for (hipStream_t *st : {&aux_stream, &aux2_stream})
         if (*st) (void)hipStreamSynchronize(*st); /* a sample in flight writes to sample_result */
     if (sample_counters) (void)hipFree(sample_counters);

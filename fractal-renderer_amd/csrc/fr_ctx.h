@@ -132,8 +132,13 @@ struct Ctx {
 
     /* GUI-sized host-buffer renders (fr_host.hip: host_render_staged): a pinned staging buffer of the library's own — the
      * device never maps, pins or DMAs into the CALLER's pages for frames up to 3840 x 2160 RGBA — and a few copy threads */
-    void *stage = nullptr;
+    void *stage = nullptr;       /* pinned host memory (hipHostMalloc, mapped) */
+    void *stage_dev = nullptr;   /* its device address: bands leave HBM through a copy KERNEL (fr_launch_copy_out) */
     size_t stage_cap = 0;
+    unsigned int *stage_counters = nullptr;     /* device: one per band in flight (4) */
+    unsigned long long *stage_flags = nullptr;  /* pinned, mapped: the bands' completion flags (4) + their device address */
+    unsigned long long *stage_flags_dev = nullptr;
+    unsigned long long stage_seq = 0;           /* flags carry the sequence number of the band that set them */
     struct CopyPool *copy_pool = nullptr;
     int reserve_stage(size_t bytes);
 

@@ -15,8 +15,8 @@
  * faulting, pinning, rendering and copying all overlap and the call costs about what the slowest of
  * them does.  Copies go straight to their final place: no staging, no second pass over the bytes.
  *
- * GUI-SIZED frames (up to 3840 x 2160 RGBA, round 4) take another road: host_render_staged.  The device DMAs into a
- * pinned buffer of the LIBRARY's and the calling thread (with a few helpers for the larger frames) copies the bytes out —
+ * GUI-SIZED frames (up to 3840 x 2160 RGBA, round 4) take another road: host_render_staged.  The device copies (a kernel of
+ * the library's own: fr_launch_copy_out) into a pinned buffer of the LIBRARY's and the calling thread (with a few helpers for the larger frames) copies the bytes out —
  * the caller's pages are never mapped, pinned or registered with the driver.  Why: the reference's GUI gets a fresh Vec
  * from every get_image and drops it after the upload (src/gui.rs:56-82); pages that the driver had registered for DMA —
  * by hipHostRegister here or by the runtime's own in-place pinning of a pageable copy — make the kernel driver
@@ -53,6 +53,7 @@ constexpr size_t kHuge = (size_t)2 << 20;
 constexpr size_t kChunk = (size_t)64 << 20;
 constexpr size_t kPinThreshold = (size_t)16 << 20; /* below: one kernel + one plain copy */
 constexpr size_t kStageMax = (size_t)40 << 20;     /* up to a 3840 x 2160 RGBA frame (33.2 MB): the staged road */
+constexpr size_t kSdmaMin = (size_t)5 << 20;       /* bands from here up leave HBM through the copy engine, smaller ones through a kernel */
 
 double now_ms() {
     using namespace std::chrono;
@@ -322,7 +323,7 @@ int copy_helpers() {
     return n;
 }
 
-/* wait for an event with little latency: poll for a while (the DMA of a band takes tens of microseconds), then sleep */
+/* wait for an event with little latency: poll for a while (the DMA of a band takes a tenth of a millisecond), then sleep */
 hipError_t wait_event(hipEvent_t e) {
     const double t0 = now_ms();
     for (;;) {
@@ -330,6 +331,25 @@ hipError_t wait_event(hipEvent_t e) {
         if (q != hipErrorNotReady) return q;
         for (int k = 0; k < 32; k++) _mm_pause();
         if (now_ms() - t0 > 0.5) return hipEventSynchronize(e);
+    }
+}
+
+/* wait until the copy kernel of a band has published `seq` in the band's flag (pinned host memory): poll — a band takes tens
+ * of microseconds — looking at the stream now and then, so that a failed launch or a lost device ends the wait */
+hipError_t wait_flag(const unsigned long long *flag, unsigned long long seq, hipStream_t st) {
+    const double t0 = now_ms();
+    double next_check = 2.0;
+    for (;;) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+        for (int k = 0; k < 16; k++) _mm_pause();
+        const double dt = now_ms() - t0;
+        if (dt > next_check) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) /* everything enqueued has run: the flag is there, or it never will be */
+                return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq ? hipSuccess : hipErrorUnknown;
+            if (q != hipErrorNotReady) return q;
+            next_check = dt + 2.0;
+        }
     }
 }
 
@@ -363,6 +383,11 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     decide_kernel(ctx, cfg, precision, y0, y1, ob, ctx.stream, true); /* ONE view (and one sample) for the frame, not one per band */
     const int pending_sample = ob.pending_sample;
     ob.pending_sample = -1;
+    std::vector<double> marks; /* FR_TRACE: host time after every step of the enqueue (which HIP call was slow?) */
+    auto mark = [&] {
+        if (trace) marks.push_back(now_ms() - t_start);
+    };
+    mark();
     auto render_on = [&](hipStream_t st, uint32_t ya, uint32_t yb, uint8_t *dst) -> int {
         fr_kparams p;
         fill_params(cfg, ob, p);
@@ -377,22 +402,40 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     hipError_t err = hipSuccess;
     const char *what = "";
     hipStream_t last = ctx.stream;
+    const unsigned long long seq0 = ctx.stage_seq + 1; /* band b publishes seq0 + b */
+    ctx.stage_seq += nb;
     for (uint32_t b = 0; b < nb && rc == FR_OK && err == hipSuccess; b++) {
         const uint32_t ya = y0 + b * band_rows, yb = ya + band_rows < y1 ? ya + band_rows : y1;
         const size_t a = row_bytes * (size_t)(ya - y0), len = row_bytes * (size_t)(yb - ya);
         hipStream_t st = (b & 1) ? ctx.stream2 : ctx.stream;
         last = st;
         rc = render_on(st, ya, yb, scratch + a);
+        mark();
         if (rc != FR_OK) break;
-        hipEvent_t ec;
-        rc = ctx.event(b, &ec);
-        if (rc != FR_OK) break;
-        /* the band's DMA behind its kernel on the SAME stream (no cross-stream event: two HIP calls fewer per band); bands
-         * alternate between two streams, so band b + 1 renders while band b travels */
-        if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, st)) != hipSuccess) what = "hipMemcpyAsync";
-        else if ((err = hipEventRecord(ec, st)) != hipSuccess) what = "hipEventRecord";
+        /* the band leaves HBM through a copy KERNEL behind its render kernel on the same stream — 16-byte stores into the
+         * pinned staging buffer, the band's sequence number into its flag when the last workgroup is done — not through the
+         * runtime's copy machinery: in a process that had moved gigabytes through registered host buffers, hipMemcpyAsync was
+         * seen to hold the calling thread for 6-8 ms now and then (FR_TRACE marks, bench.py's gui_latency block); a launch
+         * never did.  Two HIP calls a band, no event.  Bands alternate between two streams: band b + 1 renders while band b
+         * travels */
+        if (len < kSdmaMin) {
+            if ((err = fr_launch_copy_out(scratch + a, static_cast<uint8_t *>(ctx.stage_dev) + a, len, ctx.stage_counters + b,
+                                          ctx.stage_flags_dev + b, seq0 + b, st)) != hipSuccess)
+                what = "fr_launch_copy_out";
+        } else {
+            /* ... except the 6 MB bands of a 3840 x 2160 frame: the copy ENGINE moves those at the link's full rate (a band in
+             * 0.11 ms against 0.15 through the kernel's stores: 0.76 ms a frame against 0.94), and what a rare slow call costs
+             * weighs less on a frame of that size */
+            hipEvent_t ec;
+            rc = ctx.event(b, &ec);
+            if (rc != FR_OK) break;
+            if ((err = hipMemcpyAsync(stage + a, scratch + a, len, hipMemcpyDeviceToHost, st)) != hipSuccess) what = "hipMemcpyAsync";
+            else if ((err = hipEventRecord(ec, st)) != hipSuccess) what = "hipEventRecord";
+        }
+        mark();
     }
     ctx.post_sample(pending_sample, last); /* a first frame of the view: its statistics, behind the last band */
+    mark();
     const double t_enqueued = now_ms();
 
     /* the copy out: the caller alone for small bands, with the helpers from 2 MiB a band; pages the caller has never
@@ -420,11 +463,16 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     for (uint32_t b = 0; b < nb && rc == FR_OK && err == hipSuccess; b++) {
         const uint32_t ya = y0 + b * band_rows, yb = ya + band_rows < y1 ? ya + band_rows : y1;
         const size_t a = row_bytes * (size_t)(ya - y0), len = row_bytes * (size_t)(yb - ya);
-        hipEvent_t ec;
-        rc = ctx.event(b, &ec);
-        if (rc != FR_OK) break;
-        if ((err = wait_event(ec)) != hipSuccess) {
-            what = "waiting for a band's DMA";
+        if (len < kSdmaMin) {
+            err = wait_flag(ctx.stage_flags + b, seq0 + b, (b & 1) ? ctx.stream2 : ctx.stream);
+        } else {
+            hipEvent_t ec;
+            rc = ctx.event(b, &ec);
+            if (rc != FR_OK) break;
+            err = wait_event(ec);
+        }
+        if (err != hipSuccess) {
+            what = "waiting for a band to arrive in the staging buffer";
             break;
         }
         spread(out + a, stage + a, len, 0);
@@ -435,9 +483,16 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
         (void)hipStreamSynchronize(ctx.stream2);
         (void)hipStreamSynchronize(ctx.copy_stream);
     }
-    if (trace)
-        fprintf(stderr, "[fr_host] staged %zu bytes in %u bands: enqueued at %.3f ms, first touch until %.3f, copied out at %.3f\n", need, nb,
+    if (trace) {
+        fprintf(stderr, "[fr_host] staged %zu bytes in %u bands: enqueued at %.3f ms, first touch until %.3f, copied out at %.3f", need, nb,
                 t_enqueued - t_start, t_touched - t_start, now_ms() - t_start);
+        if (t_enqueued - t_start > 1.0) { /* a slow enqueue: after decide | per band: launch, memcpy, event | sample */
+            fprintf(stderr, "  [marks:");
+            for (double m : marks) fprintf(stderr, " %.3f", m);
+            fprintf(stderr, "]");
+        }
+        fprintf(stderr, "\n");
+    }
     if (rc != FR_OK) return rc;
     if (err != hipSuccess) return fail_hip(err, what);
     return FR_OK;

@@ -155,6 +155,14 @@ hipError_t fr_launch_view_sample(const fr_kparams &p, int precision, uint32_t si
                                  unsigned long long *counters, unsigned long long *result, unsigned long long tag,
                                  hipStream_t stream);
 
+/* Device -> pinned host copy BY A KERNEL, with its own completion flag (fr_host.hip: the staged road of GUI-sized frames):
+ * `bytes` from `src` (device memory) to `dst` (the device address of pinned, mapped host memory; src and dst congruent
+ * modulo 16), 16 bytes per store.  Every workgroup fences its stores at system scope and counts itself in on `counter` (a
+ * device word, zero between launches); the last one stores `seq` to `flag` (pinned, mapped host memory) — a host that
+ * polls the flag for `seq` finds the bytes there.  No runtime copy machinery, no event: two launches a band. */
+hipError_t fr_launch_copy_out(const void *src, void *dst, size_t bytes, unsigned int *counter, unsigned long long *flag,
+                              unsigned long long seq, hipStream_t stream);
+
 /* Largest palette the render kernel will stage in LDS (entries of 4 bytes): beyond it the LDS
  * footprint per one-wave workgroup would cut occupancy, and the colour is computed per pixel. */
 constexpr uint32_t FR_MAX_PALETTE_ENTRIES = 1280;

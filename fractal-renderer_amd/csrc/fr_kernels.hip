@@ -3501,7 +3501,54 @@ __global__ __launch_bounds__(256) void nu_scan_kernel(uint32_t lo, uint32_t hi, 
     atomicMax(worst_bits, (unsigned long long)fr_bits_of(worst)); /* non-negative doubles order like their bits */
 }
 
+/* see fr_kernels.h: fr_launch_copy_out */
+__global__ __launch_bounds__(256) void copy_out_kernel(const uint8_t *src, uint8_t *dst, size_t bytes, unsigned int *counter,
+                                                      unsigned long long *flag, unsigned long long seq) {
+    /* head: the bytes in front of the first 16-byte boundary of dst (src has the same alignment); tail: what is left */
+    const size_t head = (16u - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+    const size_t h = head < bytes ? head : bytes;
+    const size_t units = (bytes - h) / 16;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src + h);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst + h);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; k + 3 * stride < units; k += 4 * stride) { /* four loads in flight per lane, then four stores */
+        const uint4 a = s4[k], b = s4[k + stride], c = s4[k + 2 * stride], d = s4[k + 3 * stride];
+        d4[k] = a, d4[k + stride] = b, d4[k + 2 * stride] = c, d4[k + 3 * stride] = d;
+    }
+    for (; k < units; k += stride) d4[k] = s4[k];
+    if (blockIdx.x == 0) {
+        for (size_t k = threadIdx.x; k < h; k += 256) dst[k] = src[k];
+        const size_t t0 = h + units * 16;
+        for (size_t k = t0 + threadIdx.x; k < bytes; k += 256) dst[k] = src[k];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = atomicAdd(counter, 1u);
+        if (done + 1u == gridDim.x) { /* the last workgroup: everyone's stores are fenced; publish */
+            atomicExch(counter, 0u);
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 } /* namespace */
+
+hipError_t fr_launch_copy_out(const void *src, void *dst, size_t bytes, unsigned int *counter, unsigned long long *flag,
+                              unsigned long long seq, hipStream_t stream) {
+    if (bytes == 0) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) != (reinterpret_cast<uintptr_t>(dst) & 15u)) return hipErrorInvalidValue;
+    /* The PCIe link is the limit (~55 GB/s: ~100 KB in flight cover its latency), not the chip: at most 128 workgroups —
+     * 512 waves, 64 bytes in flight per lane — so that the next band's render kernel keeps the compute units */
+    size_t groups = (bytes / 16 + 256 * 4 - 1) / (256 * 4);
+    if (groups < 1) groups = 1;
+    if (groups > 128) groups = 128;
+    hipLaunchKernelGGL(copy_out_kernel, dim3((uint32_t)groups), dim3(256), 0, stream, static_cast<const uint8_t *>(src),
+                       static_cast<uint8_t *>(dst), bytes, counter, flag, seq);
+    return hipGetLastError();
+}
 
 bool fr_wants_work_queue(const fr_kparams &p, int tile) {
     if (p.cycle_shortcut || (p.algo != 0 && p.algo != 2)) return false;
