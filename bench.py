@@ -872,10 +872,10 @@ def supervise(args):
 
     base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--child"] + ["--child"]
 
-    def run(extra):
+    def run(extra, limit):
         p = subprocess.Popen(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            out, err = p.communicate(timeout=args.child_timeout)
+            out, err = p.communicate(timeout=limit)
             return p.returncode, out, err, False
         except subprocess.TimeoutExpired:
             try:
@@ -898,13 +898,20 @@ def supervise(args):
     for extra, what in (([], "gather as requested (--gather %s)" % args.gather), (["--gather", "peer"], "peer-to-peer DMA gather")):
         if attempts and args.gather == "peer":
             break  # the request WAS the peer gather: nothing else to fall back on
-        rc, out, err, timed_out = run(extra)
+        limit = args.child_timeout
+        if os.environ.get("FR_BENCH_TEST_STALL") == (extra[1] if extra else args.gather):
+            # test hook: only the child that is TOLD to stall gets the short limit, so a healthy child whose first
+            # `import torch` on a cold box takes a minute is not mistaken for a hung one
+            limit = float(os.environ.get("FR_BENCH_TEST_STALL_TIMEOUT", limit))
+        rc, out, err, timed_out = run(extra, limit)
         d = last_json(out)
+        if not attempts:
+            limit0 = limit
         attempts.append({"what": what, "exit_code": rc, "timed_out": timed_out,
                          "stderr_tail": err[-600:] if rc != 0 else ""})
         if rc == 0 and d is not None:
             if len(attempts) > 1:
-                d["fallback"] = {"reason": "the first child %s" % ("hung and was killed after %.0f s" % args.child_timeout
+                d["fallback"] = {"reason": "the first child %s" % ("hung and was killed after %.0f s" % limit0
                                                                      if attempts[0]["timed_out"] else
                                                                      "exited with code %d" % attempts[0]["exit_code"]),
                                  "attempts": attempts}

@@ -159,14 +159,15 @@ def test_rccl_load_failure_is_an_error_code_not_a_crash():
 def test_bench_supervisor_kills_a_stalled_child_and_falls_back():
     """VERDICT r02 #2b: plain `python3 bench.py --gpus N` runs the measurement in a fresh child process with a time
     limit; a child that hangs is killed (whole process group) and a second fresh child tries the peer-DMA gather.
-    Here the first child is made to stall (FR_BENCH_TEST_STALL=rccl) and the limit is 3 s; the fallback child then
+    Here the first child is made to stall (FR_BENCH_TEST_STALL=rccl) and ITS limit is 3 s (a healthy child keeps a
+    long one: its first `import torch` on a cold box can take a minute); the fallback child then
     reports, on this GPU-less box, that there are no devices — through the supervisor, with the fallback recorded."""
     import json
     import subprocess
     import sys
     import time
 
-    env = dict(os.environ, FR_BENCH_TEST_STALL="rccl", FR_BENCH_CHILD_TIMEOUT="3")
+    env = dict(os.environ, FR_BENCH_TEST_STALL="rccl", FR_BENCH_TEST_STALL_TIMEOUT="3", FR_BENCH_CHILD_TIMEOUT="240")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     t0 = time.time()
@@ -174,7 +175,7 @@ def test_bench_supervisor_kills_a_stalled_child_and_falls_back():
     took = time.time() - t0
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-500:])
-    assert took < 120, took
+    assert took < 280, took
     assert d["n_gpus"] == 2 and d["value"] is None and "needs 2 devices" in d["error"]
     fb = d["fallback"]
     assert "hung and was killed" in fb["reason"] and fb["attempts"][0]["timed_out"] is True
