@@ -116,8 +116,8 @@ int resolve_opts(const fr_render_opts *in, Opts &o) {
     if (!in) return FR_OK;
     if (in->size < sizeof(fr_render_opts)) return fail(FR_ERR_INVALID_ARGUMENT, "fr_render_opts.size is too small (use fr_render_opts_init)");
     if (!valid_tile(in->tile)) return fail(FR_ERR_INVALID_ARGUMENT, "opts.tile must be 0, 1, 2, 4, 8, 9, 10 ... 16, 6401, 3202, 1604 or 808");
-    if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4)
-        return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2 or 4");
+    if (in->loop_mode != -1 && in->loop_mode != 0 && in->loop_mode != 2 && in->loop_mode != 4 && in->loop_mode != 5)
+        return fail(FR_ERR_INVALID_ARGUMENT, "opts.loop_mode must be -1 (auto), 0, 2, 4 or 5");
     if (in->refill_minrun < -1 || in->refill_quit16 < -1 || in->refill_quit16 == 0 || in->refill_quit16 > 16)
         return fail(FR_ERR_INVALID_ARGUMENT, "opts: refill_minrun >= 0, 1 <= refill_quit16 <= 16 (or -1: the kernel's default)");
     o.tile = in->tile;
@@ -554,6 +554,8 @@ static double host_coord(double coord, double max, double offset, double pos, do
     return ((coord / max) - offset) / scale + pos;
 }
 
+constexpr uint32_t kSpecQuiet = 16;
+
 /* Choose the orbit-loop plan for a launch whose local grid is already set in `p`
  * (see fr_kernels.hip, "orbit loop, scaled form", for what the kernel does with it and why it is
  * exact).  loop_mode = M in {4, 2} and skip_t = T such that
@@ -564,7 +566,10 @@ static double host_coord(double coord, double max, double offset, double pos, do
 void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p) {
     p.loop_mode = 0;
     p.skip_t = 0.0;
-    const int forced = o.loop_mode;
+    p.loop_spec = 0;
+    /* 5 = automatic, but without the speculative long blocks (A/B and tests) */
+    const bool no_spec = o.loop_mode == 5;
+    const int forced = no_spec ? -1 : o.loop_mode;
     if (forced == 0) return;
     if (cfg->algo != FR_ALGO_MANDELBROT && cfg->algo != FR_ALGO_JULIA) return;
     if (p.ncols == 0 || p.nrows == 0) return;
@@ -611,6 +616,12 @@ void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p
         if (t >= 4.5 || (forced == m && t > 0.0)) {
             p.loop_mode = (uint32_t)m;
             p.skip_t = t;
+            /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY) need an escape inside a block to be visible at
+             * its end: once dist > limit^2 >= 16, with every |c| component <= limit^2 / 8, each step multiplies |z| by
+             * more than 2.9 (|z'| >= |z|^2 - sqrt(2) Cmax - rounding >= |z|^2 (3/4 - 8u), |z| > 4), so the computed
+             * distances grow from there — through +inf to NaN at worst — and the end test `NOT (T >= dist)` is true for
+             * every one of them (T < limit^2).  Quiet stretch before a wave speculates: 16 iterations. */
+            if (m == 4 && !no_spec && lim2 >= 16.0 && cmax <= lim2 / 8.0 && t < lim2) p.loop_spec = kSpecQuiet;
             return;
         }
     }
@@ -1490,8 +1501,8 @@ int fr_set_colour_filter(int enabled) {
 }
 
 int fr_set_loop_mode(int mode) {
-    if (mode != -1 && mode != 0 && mode != 2 && mode != 4)
-        return fail(FR_ERR_INVALID_ARGUMENT, "loop mode must be -1 (auto), 0, 2 or 4");
+    if (mode != -1 && mode != 0 && mode != 2 && mode != 4 && mode != 5)
+        return fail(FR_ERR_INVALID_ARGUMENT, "loop mode must be -1 (auto), 0, 2, 4 or 5");
     g_loop_mode.store(mode);
     return FR_OK;
 }

@@ -43,6 +43,11 @@ struct fr_kparams {
      * every live lane of the wave has |z|^2 <= skip_t (see fr_kernels.hip). */
     uint32_t loop_mode;
     double skip_t;
+    /* loop_mode == 4 only: a wave whose live lanes have all stayed under skip_t for this many iterations goes on in
+     * speculative blocks of FR_SPEC_M unchecked iterations that keep their start state (fr_kernels.hip:
+     * FR_SC_SPEC_BODY); 0 = never (the host could not prove that an escape inside a block is visible at its
+     * end, or was asked not to) */
+    uint32_t loop_spec;
     /* smooth == false only: palette[i] = packed r | g << 8 | b << 16 of an OUTSIDE pixel whose
      * escape index is i (0 .. iterations), built by fr_launch_palette; NULL = compute per pixel */
     const uint32_t *palette;

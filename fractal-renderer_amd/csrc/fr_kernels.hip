@@ -437,6 +437,80 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "v_mul_" SFX " %[A], %[X], %[X]\n"             \
     "v_mul_" SFX " %[B], %[Y], %[Y]\n"
 
+/* The same iteration reading the state in register set S and writing it to set D ("" = X, Y, A, B;
+ * "1" = X1, Y1, A1, B1): the speculative blocks below keep their start state by never writing to it. */
+#define FR_SC_IT_R(SFX, S, D)                              \
+    "v_add_" SFX " %[t], %[A" S "], -%[B" S "]\n"          \
+    "v_mul_" SFX " %[q], %[X" S "], %[Y" S "]\n"           \
+    "v_fma_" SFX " %[X" D "], %[t], 0.5, %[c2re]\n"        \
+    "v_add_" SFX " %[Y" D "], %[q], %[c2im]\n"             \
+    "v_mul_" SFX " %[A" D "], %[X" D "], %[X" D "]\n"      \
+    "v_mul_" SFX " %[B" D "], %[Y" D "], %[Y" D "]\n"
+#define FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S)
+
+/* Speculative long blocks (round 4).  A wave that has been QUIET for %[specq] iterations — no lane above T at any block
+ * end: waves of interior pixels, which carry 97 % of C2's work — stops paying the distance add and the compare every
+ * fourth iteration: it runs blocks of FR_SPEC_M iterations with NO check and tests `dist <= T` once at the block's end
+ * (6 + 2/M instructions per iteration: 6.125 at M = 16 against 6.5).  What makes that exact although a lane may
+ * escape in the middle of such a block:
+ *   - the block never overwrites its start state: its first iteration reads one register set and writes the other,
+ *     the remaining ones work in place there, and the next block does the same in the opposite direction;
+ *   - once dist_k > limit^2 the computed distances only grow (the host enables this only for limit^2 >= 16 and
+ *     |c| components <= limit^2 / 8: then |z'| >= |z|^2 (3/4 - 8u) > 2.9 |z|), through +inf to NaN at worst, and
+ *     v_cmp_nge (NOT "T >= dist") is true for all of them: an escape inside the block cannot pass the end test;
+ *   - a block whose end test fails is thrown away: the wave returns to the block's START state (it is still in
+ *     its registers: no copy for the set0 -> set1 block, four moves for the other) and runs the checked machinery
+ *     above from there, which finds the escape at its exact iteration; speculation stays off for the next %[specq]
+ *     iterations.  A lane merely in transit at the block's end (above T, not yet above the limit) takes the same road.
+ * Lanes that have escaped are not in EXEC and keep their final state in set 0, where the checked code left it. */
+#define FR_SC_SPEC_ENTRY(MSTR)                                                     \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    "s_cmp_lt_u32 %[si], %[sspec]\n"                                               \
+    "s_cbranch_scc1 .Lfast_%=\n"                                                   \
+    "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
+    "s_cmp_ge_u32 %[stmp], " MSTR "\n"                                             \
+    "s_cbranch_scc1 .Lspec_%=\n"                                                   \
+    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_branch .Lfast_%=\n"
+#define FR_SC_NOSPEC_ENTRY                                                         \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc1 .Lfast_%=\n"                                                   \
+    "s_branch .Ldone_%=\n"
+/* sspec = si + specq, saturating: the iteration count from which the wave may speculate (again) */
+#define FR_SC_SPEC_ARM                                                             \
+    "s_add_u32 %[sspec], %[si], %[specq]\n"                                        \
+    "s_cselect_b32 %[sspec], -1, %[sspec]\n"
+#define FR_SC_SPEC_BODY(SFX, MOV, MSTR, REST)                                      \
+    ".Lspec_%=:\n" FR_SC_IT_R(SFX, "", "1") REST(SFX, "1")                         \
+    "v_add_" SFX " %[t], %[A1], %[B1]\n"                                           \
+    "v_cmp_nge_" SFX " vcc, %[t4lim], %[t]\n"                                      \
+    "s_cbranch_vccnz .LrbA_%=\n"                                                   \
+    "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
+    "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
+    "s_cmp_ge_u32 %[stmp], " MSTR "\n"                                             \
+    "s_cbranch_scc0 .LexA_%=\n"                                                    \
+    FR_SC_IT_R(SFX, "1", "") REST(SFX, "")                                         \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                                             \
+    "v_cmp_nge_" SFX " vcc, %[t4lim], %[t]\n"                                      \
+    "s_cbranch_vccnz .LrbB_%=\n"                                                   \
+    "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
+    "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
+    "s_cmp_ge_u32 %[stmp], " MSTR "\n"                                             \
+    "s_cbranch_scc1 .Lspec_%=\n"                                                   \
+    "s_branch .Lspecout_%=\n"                                                      \
+    ".LexA_%=:\n"                                                                  \
+    MOV " %[X], %[X1]\n" MOV " %[Y], %[Y1]\n" MOV " %[A], %[A1]\n" MOV " %[B], %[B1]\n" \
+    ".Lspecout_%=:\n"                                                              \
+    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc1 .Lfast_%=\n"                                                   \
+    "s_branch .Ldone_%=\n"                                                         \
+    ".LrbB_%=:\n"                                                                  \
+    MOV " %[X], %[X1]\n" MOV " %[Y], %[Y1]\n" MOV " %[A], %[A1]\n" MOV " %[B], %[B1]\n" \
+    ".LrbA_%=:\n" FR_SC_SPEC_ARM                                                   \
+    "s_branch .Lfast_%=\n"
+
 #define FR_SC_CHECKED_STEP(SFX, TAG)               \
     FR_SC_IT(SFX)                                  \
     "v_add_" SFX " %[t], %[A], %[B]\n"             \
@@ -446,10 +520,11 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_cbranch_scc1 .Lrec" TAG "_%=\n"             \
     ".Lcont" TAG "_%=:\n"
 
-#define FR_SC_ASM(SFX, MSTR, FAST_ITS, SLOW_STEPS, SLOW_RECORDS, CYC_F, CYC_S, CYC_H)  \
+#define FR_SC_ASM(SFX, MSTR, FAST_ITS, SLOW_STEPS, SLOW_RECORDS, CYC_F, CYC_S, CYC_H, SP_INIT, SP_ARM, SP_ENTRY, SP_BODY)  \
     "s_mov_b64 %[sorig], exec\n"                                                   \
     "v_mov_b32 %[it], %[n]\n"                                                      \
     "s_mov_b32 %[si], 0\n"                                                         \
+    SP_INIT                                                                        \
     "s_cbranch_execz .Ldone_%=\n"                                                  \
     "v_add_" SFX " %[t], %[A], %[B]\n"                                                         \
     "s_and_b32 %[nrem], %[n], " MSTR "-1\n"                                        \
@@ -469,10 +544,9 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_add_u32 %[si], %[si], " MSTR "\n"                                           \
     "s_cbranch_vccnz .Lfastexit_%=\n"                                              \
     CYC_F                                                                          \
-    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
-    "s_cbranch_scc1 .Lfast_%=\n"                                                   \
-    "s_branch .Ldone_%=\n"                                                         \
+    SP_ENTRY                                                                       \
     ".Lfastexit_%=:\n"                                                             \
+    SP_ARM                                                                         \
     "s_mov_b64 %[sprev], exec\n"                                                   \
     "v_cmpx_nlt_" SFX " %[lim4], %[t]\n"                                           \
     "s_xor_b64 %[sdiff], %[sprev], exec\n"                                         \
@@ -497,9 +571,10 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_cbranch_scc0 .Ldone_%=\n"                                                   \
     CYC_S                                                                          \
     "v_cmp_lt_" SFX " vcc, %[t4lim], %[t]\n"                                       \
-    "s_cbranch_vccz .Lfast_%=\n"                                                   \
-    "s_branch .Lslow_%=\n"                                                         \
-    FR_ORBIT_RECORD("R", "0") SLOW_RECORDS CYC_H                                   \
+    "s_cbranch_vccnz .Lslow_%=\n"                                                  \
+    SP_ARM                                                                         \
+    "s_branch .Lfast_%=\n"                                                         \
+    FR_ORBIT_RECORD("R", "0") SLOW_RECORDS CYC_H SP_BODY                           \
     ".Ldone_%=:\n"                                                                 \
     "s_mov_b64 exec, %[sorig]\n"
 
@@ -541,23 +616,43 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_cbranch_scc1 .Lcyccont" TAG "_%=\n"         \
     "s_branch .Ldone_%=\n"
 
-#define FR_SC_ASM_M4_(SFX, CYC_F, CYC_S, CYC_H)                                                    \
+#define FR_SC_ASM_M4_(SFX, CYC_F, CYC_S, CYC_H, SP_INIT, SP_ARM, SP_ENTRY, SP_BODY)                 \
     FR_SC_ASM(SFX, "4", FR_SC_IT(SFX) FR_SC_IT(SFX) FR_SC_IT(SFX) FR_SC_IT(SFX),                    \
               FR_SC_CHECKED_STEP(SFX, "A") FR_SC_CHECKED_STEP(SFX, "B") FR_SC_CHECKED_STEP(SFX, "C") \
                   FR_SC_CHECKED_STEP(SFX, "D"),                                                     \
               FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1") FR_ORBIT_RECORD("C", "2")         \
                   FR_ORBIT_RECORD("D", "3"),                                                        \
-              CYC_F, CYC_S, CYC_H)
+              CYC_F, CYC_S, CYC_H, SP_INIT, SP_ARM, SP_ENTRY, SP_BODY)
 #define FR_SC_ASM_M2_(SFX, CYC_F, CYC_S, CYC_H)                                            \
     FR_SC_ASM(SFX, "2", FR_SC_IT(SFX) FR_SC_IT(SFX),                                        \
               FR_SC_CHECKED_STEP(SFX, "A") FR_SC_CHECKED_STEP(SFX, "B"),                    \
-              FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"), CYC_F, CYC_S, CYC_H)
-#define FR_SC_ASM_M4(SFX) FR_SC_ASM_M4_(SFX, "", "", "")
+              FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"), CYC_F, CYC_S, CYC_H, "", "", FR_SC_NOSPEC_ENTRY, "")
+#define FR_SC_ASM_M4(SFX) FR_SC_ASM_M4_(SFX, "", "", "", "", "", FR_SC_NOSPEC_ENTRY, "")
 #define FR_SC_ASM_M2(SFX) FR_SC_ASM_M2_(SFX, "", "", "")
+/* M = 4 with speculative blocks of FR_SPEC_M iterations (see FR_SC_SPEC_BODY) */
+#ifndef FR_SPEC_M
+#define FR_SPEC_M 16
+#endif
+#if FR_SPEC_M == 8
+#define FR_SPEC_MSTR "8"
+#define FR_SC_SPEC_REST(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S)
+#elif FR_SPEC_M == 16
+#define FR_SPEC_MSTR "16"
+#define FR_SC_SPEC_REST(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S)
+#elif FR_SPEC_M == 32
+#define FR_SPEC_MSTR "32"
+#define FR_SC_SPEC_REST(SFX, S) \
+    FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S)
+#else
+#error "FR_SPEC_M must be 8, 16 or 32"
+#endif
+#define FR_SC_ASM_M4_SPEC(SFX, MOV)                                                                 \
+    FR_SC_ASM_M4_(SFX, "", "", "", "s_mov_b32 %[sspec], %[specq]\n", FR_SC_SPEC_ARM, FR_SC_SPEC_ENTRY(FR_SPEC_MSTR), \
+                  FR_SC_SPEC_BODY(SFX, MOV, FR_SPEC_MSTR, FR_SC_SPEC_REST))
 #define FR_SC_CYC_HANDLERS(MOV) \
     FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S") FR_SC_CYC_SAVE(MOV, "F") FR_SC_CYC_SAVE(MOV, "S")
 #define FR_SC_ASM_M4_CYC(SFX, EQ, MOV) \
-    FR_SC_ASM_M4_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLERS(MOV))
+    FR_SC_ASM_M4_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLERS(MOV), "", "", FR_SC_NOSPEC_ENTRY, "")
 #define FR_SC_ASM_M2_CYC(SFX, EQ, MOV) \
     FR_SC_ASM_M2_(SFX, FR_SC_CYC_CHECK(EQ, "F"), FR_SC_CYC_CHECK(EQ, "S"), FR_SC_CYC_HANDLERS(MOV))
 
@@ -594,9 +689,12 @@ template <typename T, int M, bool CYC>
 __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, T &Y, T &A, T &B, T c2re, T c2im,
                                                      T squared, T skip_t, EpisodeCtl ctl, uint32_t &completed,
                                                      T *pXs = nullptr, T *pYs = nullptr,
-                                                     uint32_t *saved_index = nullptr) {
+                                                     uint32_t *saved_index = nullptr, uint32_t spec_quiet = 0u) {
     uint32_t it;
     T t, q;
+    T X1, Y1, A1, B1; /* M == 4 && !CYC: the second register set of the speculative blocks (FR_SC_SPEC_BODY) */
+    uint32_t sspec;
+    const uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet ? spec_quiet : 0xFFFFFFFFu); /* 0 = never */
     T Xs = CYC ? *pXs : T(0), Ys = CYC ? *pYs : T(0);
     uint32_t vsaved = 0xFFFFFFFFu; /* CYC: the run's iteration count at this lane's latest save, if any */
     uint32_t snext = 32u;          /* CYC: next save point of Brent's schedule within this run */
@@ -613,6 +711,10 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
     [c2re] "v"(c2re), [c2im] "v"(c2im), [lim4] "s"(lim4), [t4lim] "s"(t4lim), [n] "s"(n), [thr] "s"(thr),       \
         [minrun] "s"(minrun)
 #define FR_SC_OPERANDS : FR_SC_OUTPUTS : FR_SC_INPUTS : "vcc", "scc"
+#define FR_SC_OPERANDS_SPEC                                                                                     \
+    : FR_SC_OUTPUTS, [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [sspec] "=&s"(sspec)       \
+    : FR_SC_INPUTS, [specq] "s"(specq)                                                                          \
+    : "vcc", "scc"
 #define FR_SC_OPERANDS_CYC                                                                                      \
     : FR_SC_OUTPUTS, [scyc] "=&s"(scyc), [Xs] "+v"(Xs), [Ys] "+v"(Ys), [vsaved] "+v"(vsaved), [snext] "+s"(snext) \
     : FR_SC_INPUTS                                                                                              \
@@ -626,7 +728,7 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
         if constexpr (M == 4 && CYC)
             asm volatile(FR_SC_ASM_M4_CYC("f64", "v_cmp_eq_u64", "v_mov_b64") FR_SC_OPERANDS_CYC);
         else if constexpr (M == 4)
-            asm volatile(FR_SC_ASM_M4("f64") FR_SC_OPERANDS);
+            asm volatile(FR_SC_ASM_M4_SPEC("f64", "v_mov_b64") FR_SC_OPERANDS_SPEC);
         else if constexpr (CYC)
             asm volatile(FR_SC_ASM_M2_CYC("f64", "v_cmp_eq_u64", "v_mov_b64") FR_SC_OPERANDS_CYC);
         else
@@ -637,7 +739,7 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
         if constexpr (M == 4 && CYC)
             asm volatile(FR_SC_ASM_M4_CYC("f32", "v_cmp_eq_u32", "v_mov_b32") FR_SC_OPERANDS_CYC);
         else if constexpr (M == 4)
-            asm volatile(FR_SC_ASM_M4("f32") FR_SC_OPERANDS);
+            asm volatile(FR_SC_ASM_M4_SPEC("f32", "v_mov_b32") FR_SC_OPERANDS_SPEC);
         else if constexpr (CYC)
             asm volatile(FR_SC_ASM_M2_CYC("f32", "v_cmp_eq_u32", "v_mov_b32") FR_SC_OPERANDS_CYC);
         else
@@ -645,6 +747,7 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
     }
     (void)scyc;
     (void)snext;
+    (void)X1, (void)Y1, (void)A1, (void)B1, (void)sspec, (void)specq;
     if constexpr (CYC) {
         *pXs = Xs;
         *pYs = Ys;
@@ -657,11 +760,11 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
 /* recursive() from the start through the scaled loop.  Same contract as orbit(). */
 template <typename T, int M>
 __device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
-                                                 T skip_t, T &r2, T &i2) {
+                                                 T skip_t, T &r2, T &i2, uint32_t spec_quiet = 0u) {
     T X = re + re, Y = im + im, A = X * X, B = Y * Y;
     uint32_t completed;
     const uint32_t it = orbit_scaled_run<T, M, false>(iterations, X, Y, A, B, cre + cre, cim + cim, squared, skip_t,
-                                               EpisodeCtl{0, 0}, completed);
+                                               EpisodeCtl{0, 0}, completed, nullptr, nullptr, nullptr, spec_quiet);
     re = X * (T)0.5; /* exact */
     im = Y * (T)0.5;
     r2 = re * re; /* recomputed from the final position: the reference's own re*re, im*im */
@@ -674,13 +777,14 @@ __device__ __forceinline__ uint32_t orbit_scaled(uint32_t iterations, T &re, T &
  * otherwise the unscaled loop.  The choice is wave-uniform. */
 template <typename T>
 __device__ __forceinline__ uint32_t orbit_auto(uint32_t loop_mode, uint32_t iterations, T &re, T &im, T cre, T cim,
-                                               T squared, T skip_t, T &r2, T &i2, int strip_scalable = -1) {
+                                               T squared, T skip_t, T &r2, T &i2, int strip_scalable = -1,
+                                               uint32_t spec_quiet = 0u) {
     if (loop_mode != 0 && strip_scalable != 0) {
         /* admissibility: decided once per strip by the caller (1), or per call from the lanes' values */
         bool all_ok = strip_scalable == 1;
         if (strip_scalable < 0) all_ok = __ballot(!lane_is_scalable<T>(re, im, cre, cim)) == 0ull;
         if (all_ok) {
-            if (loop_mode == 4) return orbit_scaled<T, 4>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
+            if (loop_mode == 4) return orbit_scaled<T, 4>(iterations, re, im, cre, cim, squared, skip_t, r2, i2, spec_quiet);
             return orbit_scaled<T, 2>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
         }
     }
@@ -860,14 +964,14 @@ __device__ __forceinline__ void render_pixel(const fr_kparams &p, const fr_kout 
             tre = sre;
             tim = sim;
             iters = orbit_auto<double>(p.loop_mode, p.iterations, tre, tim, cre, cim, p.limit * p.limit, p.skip_t,
-                                       tr2, ti2, strip_scalable);
+                                       tr2, ti2, strip_scalable, p.loop_spec);
             zre = tre;
             zim = tim;
         } else {
             tre = (float)sre, tim = (float)sim;
             const float lim = (float)p.limit;
             iters = orbit_auto<float>(p.loop_mode, p.iterations, tre, tim, (float)cre, (float)cim, lim * lim,
-                                      (float)p.skip_t, tr2, ti2, strip_scalable);
+                                      (float)p.skip_t, tr2, ti2, strip_scalable, p.loop_spec);
             zre = (double)tre;
             zim = (double)tim;
         }
@@ -1379,15 +1483,142 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
     "s_mov_b64 %[srun], exec\n"                        \
     "s_mov_b64 exec, %[sorig]\n"
 
+/* M = 4: the same two loops with the speculative long blocks of the strip kernel's loop (FR_SC_SPEC_BODY has the argument):
+ * after %[specq] blocks in which no lane froze, the wave runs FR_SPEC_M iterations at a time with one `NOT (T >= dist)` test
+ * at their end, the first iteration writing to the second register set so that the block's start state survives; a failed
+ * test throws the block away and the checked blocks above run from its start state — they freeze the same lanes at the same
+ * iterations with the same counts as if there had been no speculation.  %[k] counts blocks of four: a speculative block is
+ * FR_SPEC_M / 4 of them.  (96 + 2) / 16 = 6.125 instructions per iteration (f32, counting per lane: 6.19) against 6.5 (6.75). */
+#define FR_FB_SPEC_ARM                                 \
+    "s_sub_u32 %[kspec], %[k], %[specq]\n"             \
+    "s_cselect_b32 %[kspec], 0, %[kspec]\n"
+#define FR_FB_SPEC_TRY(KB1, LOOP)                      \
+    "s_cmp_gt_u32 %[k], %[kspec]\n"                    \
+    "s_cbranch_scc1 " LOOP "\n"                        \
+    "s_cmp_lt_u32 %[k], " KB1 "\n"                     \
+    "s_cbranch_scc1 " LOOP "\n"
+#define FR_FB_SPEC_MOVS(MOV) MOV " %[X], %[X1]\n" MOV " %[Y], %[Y1]\n" MOV " %[A], %[A1]\n" MOV " %[B], %[B1]\n"
+/* the speculative loop; COUNT = what a successful block does for the per-lane count ("" in the handler form);
+ * KB = FR_SPEC_M / 4, KB1 = KB - 1 */
+#define FR_FB_SPEC_LOOP(SFX, MOV, REST, KB, KB1, COUNT, LOOP, DONE)     \
+    ".Lfsp_%=:\n" FR_SC_IT_R(SFX, "", "1") REST(SFX, "1")     \
+    "v_add_" SFX " %[t], %[A1], %[B1]\n"                      \
+    "v_cmp_nge_" SFX " vcc, %[t4lim], %[t]\n"                 \
+    "s_cbranch_vccnz .LfrbA_%=\n"                             \
+    COUNT                                                     \
+    "s_sub_u32 %[k], %[k], " KB "\n"                          \
+    "s_cbranch_scc1 .LfexAd_%=\n"                             \
+    "s_cmp_lt_u32 %[k], " KB1 "\n"                            \
+    "s_cbranch_scc1 .LfexA_%=\n"                              \
+    FR_SC_IT_R(SFX, "1", "") REST(SFX, "")                    \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                        \
+    "v_cmp_nge_" SFX " vcc, %[t4lim], %[t]\n"                 \
+    "s_cbranch_vccnz .LfrbB_%=\n"                             \
+    COUNT                                                     \
+    "s_sub_u32 %[k], %[k], " KB "\n"                          \
+    "s_cbranch_scc1 " DONE "\n"                               \
+    "s_cmp_lt_u32 %[k], " KB1 "\n"                            \
+    "s_cbranch_scc1 " LOOP "\n"                               \
+    "s_branch .Lfsp_%=\n"                                     \
+    ".LfexAd_%=:\n" FR_FB_SPEC_MOVS(MOV)                      \
+    "s_branch " DONE "\n"                                     \
+    ".LfexA_%=:\n" FR_FB_SPEC_MOVS(MOV)                       \
+    "s_branch " LOOP "\n"                                     \
+    ".LfrbB_%=:\n" FR_FB_SPEC_MOVS(MOV)                       \
+    ".LfrbA_%=:\n" FR_FB_SPEC_ARM                             \
+    "s_branch " LOOP "\n"
+
+#define FR_FB_SPEC_ASM(SFX, MOV, BLOCK_ITS, MSHIFT, REST, KB, KB1) \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    "s_mov_b64 exec, %[mask]\n"                        \
+    FR_FB_SPEC_ARM                                     \
+    ".Lfb_%=:\n" BLOCK_ITS                             \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "s_mov_b64 %[sprev], exec\n"                       \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_xor_b64 %[sdiff], %[sprev], exec\n"             \
+    "s_cbranch_scc1 .Lfbr_%=\n"                        \
+    ".Lfbc_%=:\n"                                      \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc1 .Lfbd_%=\n"                        \
+    FR_FB_SPEC_TRY(KB1, ".Lfb_%=")                     \
+    FR_FB_SPEC_LOOP(SFX, MOV, REST, KB, KB1, "", ".Lfb_%=", ".Lfbd_%=") \
+    ".Lfbr_%=:\n" FR_FB_SPEC_ARM                       \
+    "s_sub_u32 %[stmp], %[n0], %[k]\n"                 \
+    "s_lshl_b32 %[stmp], %[stmp], " MSHIFT "\n"        \
+    "s_add_u32 %[stmp], %[stmp], %[base]\n"            \
+    "s_mov_b64 %[sprev], exec\n"                       \
+    "s_mov_b64 exec, %[sdiff]\n"                       \
+    "v_cvt_f32_u32 %[cnt], %[stmp]\n"                  \
+    "s_mov_b64 exec, %[sprev]\n"                       \
+    "s_cbranch_execnz .Lfbc_%=\n"                      \
+    ".Lfbd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"
+
+/* per-lane count: a lane that freezes re-arms the quiet stretch through the EXEC comparison the handler form gets for free;
+ * here it costs two scalar instructions a block (s_mov + s_cmp on EXEC) */
+#define FR_FBC_SPEC_ASM(SFX, MOV, BLOCK_ITS, STEP, REST, KB, KB1, SPECSTEP) \
+    "s_mov_b64 %[sorig], exec\n"                       \
+    "s_mov_b64 exec, %[mask]\n"                        \
+    FR_FB_SPEC_ARM                                     \
+    ".Lfc_%=:\n" BLOCK_ITS                             \
+    "v_add_" SFX " %[t], %[A], %[B]\n"                 \
+    "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
+    "s_mov_b64 %[sprev], exec\n"                       \
+    "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
+    "s_cbranch_execz .Lfcd_%=\n"                       \
+    "s_cmp_eq_u64 %[sprev], exec\n"                    \
+    "s_cbranch_scc0 .Lfcr_%=\n"                        \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc1 .Lfcd_%=\n"                        \
+    FR_FB_SPEC_TRY(KB1, ".Lfc_%=")                     \
+    FR_FB_SPEC_LOOP(SFX, MOV, REST, KB, KB1, "v_add_f32 %[cnt], " SPECSTEP ", %[cnt]\n", ".Lfc_%=", ".Lfcd_%=") \
+    ".Lfcr_%=:\n" FR_FB_SPEC_ARM                       \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_cbranch_scc0 .Lfc_%=\n"                         \
+    ".Lfcd_%=:\n"                                      \
+    "s_mov_b64 %[srun], exec\n"                        \
+    "s_mov_b64 exec, %[sorig]\n"
+
+#if FR_SPEC_M == 8
+#define FR_SPEC_KB "2"
+#define FR_SPEC_KB1 "1"
+#define FR_SPEC_STEP "0x41000000" /* 8.0f: a literal, VOP2 takes it as src0 */
+#elif FR_SPEC_M == 16
+#define FR_SPEC_KB "4"
+#define FR_SPEC_KB1 "3"
+#define FR_SPEC_STEP "0x41800000" /* 16.0f: a literal, VOP2 takes it as src0 */
+#else
+#define FR_SPEC_KB "8"
+#define FR_SPEC_KB1 "7"
+#define FR_SPEC_STEP "0x42000000" /* 32.0f */
+#endif
+
 template <typename T, int M>
 __device__ __forceinline__ unsigned long long first_blocks(unsigned long long mask, uint32_t nblocks, uint32_t done_before, T &X, T &Y,
                                                            T &A, T &B, T &t, float &cnt, T c2re, T c2im,
-                                                           typename UBits<T>::type t4lim) {
+                                                           typename UBits<T>::type t4lim, uint32_t spec_quiet_blocks = 0u) {
     T q;
+    T X1, Y1, A1, B1; /* M == 4: the second register set of the speculative blocks */
+    uint32_t kspec;
+    const uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet_blocks ? spec_quiet_blocks : 0xFFFFFFFFu); /* 0 = never */
     unsigned long long sorig, srun, sprev, sdiff;
+    (void)X1, (void)Y1, (void)A1, (void)B1, (void)kspec, (void)specq;
+#define FR_FB_SPEC_OUT , [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [kspec] "=&s"(kspec)
     if constexpr (sizeof(T) == 4) {
         uint32_t kc = __builtin_amdgcn_readfirstlane(nblocks) - 1u;
-        (void)done_before, (void)sprev, (void)sdiff;
+        (void)done_before, (void)sdiff;
+        if constexpr (M == 4) {
+            asm volatile(FR_FBC_SPEC_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0",
+                                         FR_SC_SPEC_REST, FR_SPEC_KB, FR_SPEC_KB1, FR_SPEC_STEP)
+                         : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),
+                           [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [k] "+s"(kc) FR_FB_SPEC_OUT
+                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [specq] "s"(specq)
+                         : "vcc", "scc");
+            return srun;
+        }
+        (void)sprev;
 #define FR_FBC_OPERANDS                                                                                          \
     : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),            \
       [sorig] "=&s"(sorig), [srun] "=&s"(srun), [k] "+s"(kc)                                                     \
@@ -1409,7 +1640,14 @@ __device__ __forceinline__ unsigned long long first_blocks(unsigned long long ma
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
         if constexpr (M == 4)
-            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "2") FR_FB_OPERANDS);
+            asm volatile(FR_FB_SPEC_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "2",
+                                        FR_SC_SPEC_REST, FR_SPEC_KB, FR_SPEC_KB1)
+                         : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),
+                           [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [k] "+s"(k),
+                           [stmp] "=&s"(stmp) FR_FB_SPEC_OUT
+                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(n0), [base] "s"(base),
+                           [specq] "s"(specq)
+                         : "vcc", "scc");
         else
             asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "1") FR_FB_OPERANDS);
     }
@@ -1648,6 +1886,11 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     /* the asm path runs a whole first episode and up to 64 exact iterations without looking at the cap */
     const bool fast_tiles = k1 % (uint32_t)M == 0u && k1 + 64u <= cap;
     const uint32_t nblk1 = k1 / (uint32_t)M;
+    uint32_t spec_blocks; /* quiet blocks before a wave speculates in the later episodes (first_blocks); 0 = never */
+    {
+        FR_COLD_PARAMS(kp);
+        spec_blocks = kp->loop_spec / (uint32_t)M;
+    }
     /* the strip's tiles: `ntiles` lie (partly) inside the image, the first `nfull` of them with all 8 columns */
     const uint32_t cols_left = ncols - tile0 * 8u; /* > 0: the grid has no workgroup past the right edge */
     const uint32_t ntiles = (cols_left + 7u) / 8u < (uint32_t)kStripTiles ? (cols_left + 7u) / 8u : (uint32_t)kStripTiles;
@@ -1745,7 +1988,7 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                             const uint32_t left = cap - done;
                             const uint32_t nblk = (left < len ? left : len) / (uint32_t)M;
                             if (nblk == 0u) break; /* fewer than M iterations to the cap: the exact loop below runs them */
-                            run = first_blocks<T, M>(run, nblk, done, X, Y, A, B, t, cnt, c2re, c2im, t4lim);
+                            run = first_blocks<T, M>(run, nblk, done, X, Y, A, B, t, cnt, c2re, c2im, t4lim, spec_blocks);
                             done += nblk * (uint32_t)M;
                         } else {
                             done = k1;
@@ -1983,7 +2226,7 @@ __device__ __forceinline__ void refill_patch(const fr_kparams &p, const fr_kout 
                 it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
             else
                 it = orbit_scaled_run<T, FORM, CYC>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed, &xs, &ys,
-                                                    &saved_index);
+                                                    &saved_index, p.loop_spec);
         }
         /* ---- retire the lanes that finished */
         if (busy) {
