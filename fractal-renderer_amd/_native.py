@@ -205,6 +205,8 @@ PROTOTYPES = {
     "fr_last_kernel_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "fr_set_tile": (C.c_int, [C.c_int]),
     "fr_set_loop_mode": (C.c_int, [C.c_int]),
+    "fr_debug_loop_plan": (C.c_int, [C.POINTER(fr_config), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_uint32)]),
     "fr_set_palette": (C.c_int, [C.c_int]),
     "fr_set_cycle_shortcut": (C.c_int, [C.c_int]),
     "fr_set_refill_policy": (C.c_int, [C.c_int, C.c_int]),

@@ -621,7 +621,10 @@ void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p
              * more than 2.9 (|z'| >= |z|^2 - sqrt(2) Cmax - rounding >= |z|^2 (3/4 - 8u), |z| > 4), so the computed
              * distances grow from there — through +inf to NaN at worst — and the end test `NOT (T >= dist)` is true for
              * every one of them (T < limit^2).  Quiet stretch before a wave speculates: 16 iterations. */
-            if (m == 4 && !no_spec && lim2 >= 16.0 && cmax <= lim2 / 8.0 && t < lim2) p.loop_spec = kSpecQuiet;
+            if (m == 4 && !no_spec && lim2 >= 16.0 && cmax <= lim2 / 8.0 && t < lim2) {
+                static const int dbg = getenv("FR_DEBUG_SPEC_QUIET") ? atoi(getenv("FR_DEBUG_SPEC_QUIET")) : 0; /* tuning aid */
+                p.loop_spec = dbg > 0 ? (uint32_t)dbg : kSpecQuiet;
+            }
             return;
         }
     }
@@ -1536,6 +1539,25 @@ int fr_debug_sample_view(const fr_config *cfg, int precision, double out[8]) {
     for (int k = 0; k < 6; k++) out[k] = st[k];
     out[6] = st[1] > 0.0 ? st[0] / st[1] : 0.0;
     out[7] = st[6];
+    return FR_OK;
+}
+
+/* the orbit-loop plan of (cfg, precision) rendered as one launch, with the process's current selectors: host arithmetic only
+ * (no device needed), so that the CPU suite can pin when the scaled loop and its speculative blocks are allowed */
+int fr_debug_loop_plan(const fr_config *cfg, int precision, uint32_t *loop_mode, double *skip_t, uint32_t *spec_quiet) {
+    if (!cfg || !loop_mode || !skip_t || !spec_quiet) return fail(FR_ERR_INVALID_ARGUMENT, "NULL argument");
+    int rc = check_precision(precision);
+    if (rc != FR_OK) return rc;
+    const Opts o = default_opts();
+    fr_kparams p;
+    fill_params(cfg, o, p);
+    p.nrows = cfg->height;
+    p.block_rows = cfg->height ? cfg->height : 1;
+    p.y_stride = 0;
+    plan_loop(cfg, precision, o, p);
+    *loop_mode = p.loop_mode;
+    *skip_t = p.skip_t;
+    *spec_quiet = p.loop_spec;
     return FR_OK;
 }
 

@@ -508,7 +508,10 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     "s_branch .Ldone_%=\n"                                                         \
     ".LrbB_%=:\n"                                                                  \
     MOV " %[X], %[X1]\n" MOV " %[Y], %[Y1]\n" MOV " %[A], %[A1]\n" MOV " %[B], %[B1]\n" \
-    ".LrbA_%=:\n" FR_SC_SPEC_ARM                                                   \
+    ".LrbA_%=:\n"                                                                  \
+    "s_lshl_b32 %[specq], %[specq], 1\n"                                           \
+    "s_min_u32 %[specq], %[specq], 0x8000\n"                                       \
+    FR_SC_SPEC_ARM                                                                 \
     "s_branch .Lfast_%=\n"
 
 #define FR_SC_CHECKED_STEP(SFX, TAG)               \
@@ -694,7 +697,7 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
     T t, q;
     T X1, Y1, A1, B1; /* M == 4 && !CYC: the second register set of the speculative blocks (FR_SC_SPEC_BODY) */
     uint32_t sspec;
-    const uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet ? spec_quiet : 0xFFFFFFFFu); /* 0 = never */
+    uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet ? spec_quiet : 0xFFFFFFFFu); /* 0 = never; doubles with every block thrown away */
     T Xs = CYC ? *pXs : T(0), Ys = CYC ? *pYs : T(0);
     uint32_t vsaved = 0xFFFFFFFFu; /* CYC: the run's iteration count at this lane's latest save, if any */
     uint32_t snext = 32u;          /* CYC: next save point of Brent's schedule within this run */
@@ -712,8 +715,9 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
         [minrun] "s"(minrun)
 #define FR_SC_OPERANDS : FR_SC_OUTPUTS : FR_SC_INPUTS : "vcc", "scc"
 #define FR_SC_OPERANDS_SPEC                                                                                     \
-    : FR_SC_OUTPUTS, [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [sspec] "=&s"(sspec)       \
-    : FR_SC_INPUTS, [specq] "s"(specq)                                                                          \
+    : FR_SC_OUTPUTS, [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [sspec] "=&s"(sspec),      \
+      [specq] "+s"(specq)                                                                                       \
+    : FR_SC_INPUTS                                                                                              \
     : "vcc", "scc"
 #define FR_SC_OPERANDS_CYC                                                                                      \
     : FR_SC_OUTPUTS, [scyc] "=&s"(scyc), [Xs] "+v"(Xs), [Ys] "+v"(Ys), [vsaved] "+v"(vsaved), [snext] "+s"(snext) \
@@ -1525,7 +1529,10 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
     ".LfexA_%=:\n" FR_FB_SPEC_MOVS(MOV)                       \
     "s_branch " LOOP "\n"                                     \
     ".LfrbB_%=:\n" FR_FB_SPEC_MOVS(MOV)                       \
-    ".LfrbA_%=:\n" FR_FB_SPEC_ARM                             \
+    ".LfrbA_%=:\n"                                            \
+    "s_lshl_b32 %[specq], %[specq], 1\n"                      \
+    "s_min_u32 %[specq], %[specq], 0x2000\n"                  \
+    FR_FB_SPEC_ARM                                            \
     "s_branch " LOOP "\n"
 
 #define FR_FB_SPEC_ASM(SFX, MOV, BLOCK_ITS, MSHIFT, REST, KB, KB1) \
@@ -1602,10 +1609,10 @@ __device__ __forceinline__ unsigned long long first_blocks(unsigned long long ma
     T q;
     T X1, Y1, A1, B1; /* M == 4: the second register set of the speculative blocks */
     uint32_t kspec;
-    const uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet_blocks ? spec_quiet_blocks : 0xFFFFFFFFu); /* 0 = never */
+    uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet_blocks ? spec_quiet_blocks : 0xFFFFFFFFu); /* 0 = never; doubles with every block thrown away */
     unsigned long long sorig, srun, sprev, sdiff;
     (void)X1, (void)Y1, (void)A1, (void)B1, (void)kspec, (void)specq;
-#define FR_FB_SPEC_OUT , [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [kspec] "=&s"(kspec)
+#define FR_FB_SPEC_OUT , [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [kspec] "=&s"(kspec), [specq] "+s"(specq)
     if constexpr (sizeof(T) == 4) {
         uint32_t kc = __builtin_amdgcn_readfirstlane(nblocks) - 1u;
         (void)done_before, (void)sdiff;
@@ -1614,7 +1621,7 @@ __device__ __forceinline__ unsigned long long first_blocks(unsigned long long ma
                                          FR_SC_SPEC_REST, FR_SPEC_KB, FR_SPEC_KB1, FR_SPEC_STEP)
                          : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),
                            [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [k] "+s"(kc) FR_FB_SPEC_OUT
-                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [specq] "s"(specq)
+                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask)
                          : "vcc", "scc");
             return srun;
         }
@@ -1645,8 +1652,7 @@ __device__ __forceinline__ unsigned long long first_blocks(unsigned long long ma
                          : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),
                            [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [k] "+s"(k),
                            [stmp] "=&s"(stmp) FR_FB_SPEC_OUT
-                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(n0), [base] "s"(base),
-                           [specq] "s"(specq)
+                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(n0), [base] "s"(base)
                          : "vcc", "scc");
         else
             asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "1") FR_FB_OPERANDS);

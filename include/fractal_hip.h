@@ -420,8 +420,17 @@ int fr_set_colour_filter(int enabled);
 /* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled
  * loop with an escape check every iteration; 4 / 2 = the scaled loop that checks every 4th / 2nd
  * iteration, used only where it is provably bit-identical (otherwise the call still falls back to
- * 0).  Every mode produces the same bytes. */
+ * 0).  With 4 (and under -1 wherever 4 is chosen) a wave whose lanes have all stayed far inside the
+ * limit for 16 iterations goes on in speculative blocks of 16 unchecked iterations that keep their start
+ * state in a second register set: one test at the block's end, the block thrown away and re-run with
+ * checks if it fails (only where limit^2 >= 16 and every |c| component <= limit^2 / 8: an orbit past
+ * the limit then grows monotonically, so an escape inside a block cannot be missed at its end).
+ * 5 = automatic without those speculative blocks (A/B).  Every mode produces the same bytes. */
 int fr_set_loop_mode(int mode);
+/* Tool / test hook, host arithmetic only (works without a device): the loop plan of (cfg, precision) as one launch
+ * under the current selectors — *loop_mode = 0 / 2 / 4 as above, *skip_t = the squared distance under which escape
+ * checks are skipped, *spec_quiet = iterations a wave must stay under it before it speculates (0 = never). */
+int fr_debug_loop_plan(const fr_config *cfg, int precision, uint32_t *loop_mode, double *skip_t, uint32_t *spec_quiet);
 
 /* Test hook (not part of the reference surface): elementwise DEVICE arithmetic over host arrays —
  * which = 0: the kernels' software log2, 1: sqrt, 2: in[k] / in[(k+1) % n], 3: the `as u8` cast —
