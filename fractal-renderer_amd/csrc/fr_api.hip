@@ -570,14 +570,12 @@ void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p
     /* 5 = automatic, but without the speculative long blocks (A/B and tests) */
     const bool no_spec = o.loop_mode == 5;
     const int forced = no_spec ? -1 : o.loop_mode;
-    if (forced == 0) return;
     if (cfg->algo != FR_ALGO_MANDELBROT && cfg->algo != FR_ALGO_JULIA) return;
     if (p.ncols == 0 || p.nrows == 0) return;
     const bool f32 = precision == FR_PRECISION_F32;
     const double range_hi = f32 ? 0x1p30 : 0x1p400;
     const double slack = f32 ? 1.0 + 0x1p-18 : 1.0 + 0x1p-30;
-    if (!(std::fabs(cfg->limit) <= range_hi)) return; /* also rejects NaN */
-    double lim2;
+    double lim2; /* limit^2 as the kernels compute it (may be +inf or NaN) */
     if (f32) {
         const float lf = (float)cfg->limit;
         lim2 = (double)(lf * lf);
@@ -585,22 +583,34 @@ void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p
         lim2 = cfg->limit * cfg->limit;
     }
     auto mag = [f32](double v) { return std::fabs(f32 ? (double)(float)v : v); };
-    double cmax;
-    if (cfg->algo == FR_ALGO_JULIA) {
-        cmax = std::fmax(mag(cfg->julia_set.re), mag(cfg->julia_set.im));
-    } else {
-        /* c = pixel coordinate; the map is monotone in x and in y, so the extremes are at the ends */
-        const double w = (double)cfg->width, h = (double)cfg->height;
-        const uint64_t x_last = (uint64_t)p.x_first + (uint64_t)(p.ncols - 1) * p.x_stride;
-        const uint32_t r_last = p.nrows - 1;
-        const uint64_t y_last = (uint64_t)p.y_first + (uint64_t)(r_last / p.block_rows) * p.y_stride + r_last % p.block_rows;
-        if (x_last > 0xFFFFFFFFull || y_last > 0xFFFFFFFFull) return;
-        cmax = 0.0;
-        for (double x : {(double)p.x_first, (double)x_last})
-            cmax = std::fmax(cmax, mag(host_coord(x, h, (w / h) / 2.0, cfg->pos.re, cfg->scale.re)));
-        for (double y : {(double)p.y_first, (double)y_last})
-            cmax = std::fmax(cmax, mag(host_coord(y, h, 0.5, cfg->pos.im, cfg->scale.im)));
+    /* the largest start component of the launch: the map is monotone in x and in y, so the extremes are at the ends */
+    const double w = (double)cfg->width, h = (double)cfg->height;
+    const uint64_t x_last = (uint64_t)p.x_first + (uint64_t)(p.ncols - 1) * p.x_stride;
+    const uint32_t r_last = p.nrows - 1;
+    const uint64_t y_last = (uint64_t)p.y_first + (uint64_t)(r_last / p.block_rows) * p.y_stride + r_last % p.block_rows;
+    if (x_last > 0xFFFFFFFFull || y_last > 0xFFFFFFFFull) return;
+    auto nmax = [](double a, double b) { return (a != a || b != b) ? NAN : std::fmax(a, b); }; /* a NaN stays (std::fmax drops it) */
+    double smax = 0.0;
+    for (double x : {(double)p.x_first, (double)x_last})
+        smax = nmax(smax, mag(host_coord(x, h, (w / h) / 2.0, cfg->pos.re, cfg->scale.re)));
+    for (double y : {(double)p.y_first, (double)y_last})
+        smax = nmax(smax, mag(host_coord(y, h, 0.5, cfg->pos.im, cfg->scale.im)));
+    /* Mandelbrot: c = the pixel's coordinate; Julia: c = julia_set (calc/src/lib.rs:209-210) */
+    const double cmax = cfg->algo == FR_ALGO_JULIA ? nmax(mag(cfg->julia_set.re), mag(cfg->julia_set.im)) : smax;
+    /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY, FR_ORBIT_ASM, FR_FB_SPEC_LOOP) — in whichever loop form a
+     * wave runs — need an escape inside a block to be visible at its end: once dist > limit^2 >= 16, with every |c|
+     * component <= limit^2 / 8, each step multiplies |z| by more than 2.9 (|z'| >= |z|^2 - sqrt(2) Cmax - rounding >=
+     * |z|^2 (3/4 - 8u), |z| > 4), so the computed distances grow from there — through +inf to NaN at worst — and the end
+     * test `NOT (bound >= dist)` (bound = T or limit^2, both <= limit^2) is true for every one of them.  limit^2 must be
+     * finite with room above it (an orbit must pass it BEFORE anything overflows: no NaN without an escape), and the
+     * starts finite (a NaN start never escapes and would fail every block's test).  Quiet stretch before a wave
+     * speculates: 16 iterations, doubling with every block thrown away. */
+    if (!no_spec && lim2 >= 16.0 && lim2 <= (f32 ? 0x1p100 : 0x1p1000) && cmax <= lim2 / 8.0 && smax <= (f32 ? 0x1p120 : 0x1p1000)) {
+        static const int dbg = getenv("FR_DEBUG_SPEC_QUIET") ? atoi(getenv("FR_DEBUG_SPEC_QUIET")) : 0; /* tuning aid */
+        p.loop_spec = dbg > 0 ? (uint32_t)dbg : kSpecQuiet;
     }
+    if (forced == 0) return;
+    if (!(std::fabs(cfg->limit) <= range_hi)) return; /* also rejects NaN */
     if (!(cmax <= range_hi)) return; /* NaN / inf / huge */
     for (int m : {4, 2}) {
         if (forced > 0 && forced != m) continue;
@@ -616,15 +626,7 @@ void plan_loop(const fr_config *cfg, int precision, const Opts &o, fr_kparams &p
         if (t >= 4.5 || (forced == m && t > 0.0)) {
             p.loop_mode = (uint32_t)m;
             p.skip_t = t;
-            /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY) need an escape inside a block to be visible at
-             * its end: once dist > limit^2 >= 16, with every |c| component <= limit^2 / 8, each step multiplies |z| by
-             * more than 2.9 (|z'| >= |z|^2 - sqrt(2) Cmax - rounding >= |z|^2 (3/4 - 8u), |z| > 4), so the computed
-             * distances grow from there — through +inf to NaN at worst — and the end test `NOT (T >= dist)` is true for
-             * every one of them (T < limit^2).  Quiet stretch before a wave speculates: 16 iterations. */
-            if (m == 4 && !no_spec && lim2 >= 16.0 && cmax <= lim2 / 8.0 && t < lim2) {
-                static const int dbg = getenv("FR_DEBUG_SPEC_QUIET") ? atoi(getenv("FR_DEBUG_SPEC_QUIET")) : 0; /* tuning aid */
-                p.loop_spec = dbg > 0 ? (uint32_t)dbg : kSpecQuiet;
-            }
+            if (!(t < lim2)) p.loop_spec = 0; /* (cannot happen: T <= sqrt(limit^2 / 2); the scaled blocks test against T) */
             return;
         }
     }

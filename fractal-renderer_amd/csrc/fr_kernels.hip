@@ -313,8 +313,8 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
  * kernel — when at most `thr` lanes are still running and at least `minrun` iterations have been
  * done, so that the idle lanes can be given new pixels (thr = 0 and minrun = 0 reproduce "run until
  * every lane has escaped").  %[si] leaves the block holding the number of iterations completed. */
-#define FR_ORBIT_RECORD(TAG, OFFSET)               \
-    ".Lrec" TAG "_%=:\n"                           \
+#define FR_ORBIT_RECORD_(TAG, OFFSET, REARM)       \
+    ".Lrec" TAG "_%=:\n" REARM                     \
     "s_add_u32 %[stmp], %[si], " OFFSET "\n"       \
     "s_mov_b64 %[sprev], exec\n"                   \
     "s_mov_b64 exec, %[sdiff]\n"                   \
@@ -329,11 +329,61 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
     ".Lquit" TAG "_%=:\n"                          \
     "s_add_u32 %[si], %[stmp], 1\n"                \
     "s_branch .Ldone_%=\n"
+#define FR_ORBIT_RECORD(TAG, OFFSET) FR_ORBIT_RECORD_(TAG, OFFSET, "")
+/* the unscaled loop's form: a lane that escapes re-arms the quiet stretch before the wave may speculate (FR_ORBIT_ASM) */
+#define FR_ORBIT_RECORD_A(TAG, OFFSET)             \
+    FR_ORBIT_RECORD_(TAG, OFFSET, "s_add_u32 %[sspec], %[si], %[specq]\n" "s_cselect_b32 %[sspec], -1, %[sspec]\n")
 
-#define FR_ORBIT_ASM(SFX)                                                          \
+/* length of a speculative block (FR_ORBIT_ASM, FR_SC_SPEC_BODY, FR_FB_SPEC_LOOP): FR_SPEC_M iterations */
+#ifndef FR_SPEC_M
+#define FR_SPEC_M 16
+#endif
+#if FR_SPEC_M == 8
+#define FR_SPEC_MSTR "8"
+#define FR_SC_SPEC_REST(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S)
+#define FR_ORBIT_SPEC_REST(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R(SFX, S, S) FR_ORBIT_IT_R(SFX, S, S)
+#elif FR_SPEC_M == 16
+#define FR_SPEC_MSTR "16"
+#define FR_SC_SPEC_REST(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S)
+#define FR_ORBIT_SPEC_REST(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S)
+#elif FR_SPEC_M == 32
+#define FR_SPEC_MSTR "32"
+#define FR_SC_SPEC_REST(SFX, S) \
+    FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S)
+#define FR_ORBIT_SPEC_REST(SFX, S) \
+    FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R5(SFX, S) FR_ORBIT_IT_R(SFX, S, S)
+#else
+#error "FR_SPEC_M must be 8, 16 or 32"
+#endif
+/* The unscaled iteration without its distance add and compare, reading the state in register set S and writing it to
+ * set D ("" = re, im, r2, i2; "1" = re1, im1, r21, i21): 7 vector instructions. */
+#define FR_ORBIT_IT_R(SFX, S, D)                           \
+    "v_add_" SFX " %[t], %[r2" S "], -%[i2" S "]\n"        \
+    "v_add_" SFX " %[x], %[re" S "], %[re" S "]\n"         \
+    "v_add_" SFX " %[re" D "], %[t], %[cre]\n"             \
+    "v_mul_" SFX " %[x], %[x], %[im" S "]\n"               \
+    "v_add_" SFX " %[im" D "], %[x], %[cim]\n"             \
+    "v_mul_" SFX " %[r2" D "], %[re" D "], %[re" D "]\n"   \
+    "v_mul_" SFX " %[i2" D "], %[im" D "], %[im" D "]\n"
+#define FR_ORBIT_IT_R5(SFX, S) \
+    FR_ORBIT_IT_R(SFX, S, S) FR_ORBIT_IT_R(SFX, S, S) FR_ORBIT_IT_R(SFX, S, S) FR_ORBIT_IT_R(SFX, S, S) FR_ORBIT_IT_R(SFX, S, S)
+#define FR_ORBIT_SPEC_MOVS(MOV) \
+    MOV " %[re], %[re1]\n" MOV " %[im], %[im1]\n" MOV " %[r2], %[r21]\n" MOV " %[i2], %[i21]\n"
+
+/* The loop of recursive() as written (9 vector instructions per iteration), with the speculative long blocks of the scaled
+ * loop below (FR_SC_SPEC_BODY has the argument; round 4): this is the loop of every wave with a lane the scaled form is not
+ * proven for — a Julia constant with a zero component (c = -1, i, 0.25: the named sets), the strip on the real axis — and
+ * of launches whose limit leaves no room for skipped checks.  A wave in which no lane has escaped for %[specq] iterations
+ * runs FR_SPEC_M iterations without the distance add and the compare (7 instructions each), the first one writing to the
+ * second register set, and tests `NOT (limit^2 >= dist)` once at the end — true for an orbit that escaped inside the block
+ * (it only grows from there, through +inf to NaN at worst: the host's conditions, plan_loop) — in which case the block is
+ * thrown away and run again with checks from its intact start state.  There is no early warning here (no T): every escape
+ * after a quiet stretch costs one block, and the stretch doubles each time. */
+#define FR_ORBIT_ASM(SFX, MOV)                                                     \
     "s_mov_b64 %[sorig], exec\n"                                                   \
     "v_mov_b32 %[it], %[n]\n"                                                      \
     "s_mov_b32 %[si], 0\n"                                                         \
+    "s_mov_b32 %[sspec], %[specq]\n"                                               \
     "s_cbranch_execz .Ldone_%=\n"                                                  \
     "s_and_b32 %[nrem], %[n], 3\n"                                                 \
     "s_cbranch_scc0 .Lmainentry_%=\n"                                              \
@@ -347,10 +397,46 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
     ".Lmain_%=:\n" FR_ORBIT_STEP(SFX, "A") FR_ORBIT_STEP(SFX, "B") FR_ORBIT_STEP(SFX, "C") FR_ORBIT_STEP(SFX, "D") \
     "s_add_u32 %[si], %[si], 4\n"                                                  \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
+    "s_cmp_lt_u32 %[si], %[sspec]\n"                                               \
+    "s_cbranch_scc1 .Lmain_%=\n"                                                   \
+    "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
+    "s_cmp_ge_u32 %[stmp], " FR_SPEC_MSTR "\n"                                     \
+    "s_cbranch_scc1 .Lspec_%=\n"                                                   \
+    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_branch .Lmain_%=\n"                                                         \
+    ".Lspec_%=:\n" FR_ORBIT_IT_R(SFX, "", "1") FR_ORBIT_SPEC_REST(SFX, "1")        \
+    "v_add_" SFX " %[t], %[r21], %[i21]\n"                                         \
+    "v_cmp_nge_" SFX " vcc, %[lim2], %[t]\n"                                       \
+    "s_cbranch_vccnz .LrbA_%=\n"                                                   \
+    "s_add_u32 %[si], %[si], " FR_SPEC_MSTR "\n"                                   \
+    "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
+    "s_cmp_ge_u32 %[stmp], " FR_SPEC_MSTR "\n"                                     \
+    "s_cbranch_scc0 .LexA_%=\n"                                                    \
+    FR_ORBIT_IT_R(SFX, "1", "") FR_ORBIT_SPEC_REST(SFX, "")                        \
+    "v_add_" SFX " %[t], %[r2], %[i2]\n"                                           \
+    "v_cmp_nge_" SFX " vcc, %[lim2], %[t]\n"                                       \
+    "s_cbranch_vccnz .LrbB_%=\n"                                                   \
+    "s_add_u32 %[si], %[si], " FR_SPEC_MSTR "\n"                                   \
+    "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
+    "s_cmp_ge_u32 %[stmp], " FR_SPEC_MSTR "\n"                                     \
+    "s_cbranch_scc1 .Lspec_%=\n"                                                   \
+    "s_branch .Lspecout_%=\n"                                                      \
+    ".LexA_%=:\n" FR_ORBIT_SPEC_MOVS(MOV)                                          \
+    ".Lspecout_%=:\n"                                                              \
+    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc1 .Lmain_%=\n"                                                   \
     "s_branch .Ldone_%=\n"                                                         \
-    FR_ORBIT_RECORD("R", "0") FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1")  \
-    FR_ORBIT_RECORD("C", "2") FR_ORBIT_RECORD("D", "3")                            \
+    ".LrbB_%=:\n" FR_ORBIT_SPEC_MOVS(MOV)                                          \
+    ".LrbA_%=:\n"                                                                  \
+    "s_lshl_b32 %[specq], %[specq], 1\n"                                           \
+    "s_min_u32 %[specq], %[specq], 0x8000\n"                                       \
+    "s_add_u32 %[sspec], %[si], %[specq]\n"                                        \
+    "s_cselect_b32 %[sspec], -1, %[sspec]\n"                                       \
+    "s_branch .Lmain_%=\n"                                                         \
+    FR_ORBIT_RECORD_A("R", "0") FR_ORBIT_RECORD_A("A", "0") FR_ORBIT_RECORD_A("B", "1") \
+    FR_ORBIT_RECORD_A("C", "2") FR_ORBIT_RECORD_A("D", "3")                         \
     ".Ldone_%=:\n"                                                                 \
     "s_mov_b64 exec, %[sorig]\n"
 
@@ -366,17 +452,20 @@ struct EpisodeCtl {
  * is still running; `completed` (wave-uniform) = iterations every still-running lane has done. */
 template <typename T>
 __device__ __forceinline__ uint32_t orbit_run(uint32_t iterations, T &re, T &im, T cre, T cim, T squared, T &r2,
-                                              T &i2, EpisodeCtl ctl, uint32_t &completed) {
+                                              T &i2, EpisodeCtl ctl, uint32_t &completed, uint32_t spec_quiet = 0u) {
     uint32_t it;
     T t, x;
+    T re1, im1, r21, i21; /* the second register set of the speculative blocks */
     unsigned long long sorig, sprev, sdiff;
-    uint32_t si, stmp, nrem, scnt;
+    uint32_t si, stmp, nrem, scnt, sspec;
+    uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet ? spec_quiet : 0xFFFFFFFFu); /* 0 = never; doubles with every block thrown away */
     const uint32_t n = __builtin_amdgcn_readfirstlane(iterations);
     const uint32_t thr = __builtin_amdgcn_readfirstlane(ctl.thr), minrun = __builtin_amdgcn_readfirstlane(ctl.minrun);
 #define FR_ORBIT_OPERANDS                                                                                          \
     : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t), [x] "=&v"(x),      \
       [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),        \
-      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt)                                                                       \
+      [nrem] "=&s"(nrem), [scnt] "=&s"(scnt), [re1] "=&v"(re1), [im1] "=&v"(im1), [r21] "=&v"(r21),                \
+      [i21] "=&v"(i21), [sspec] "=&s"(sspec), [specq] "+s"(specq)                                                  \
     : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n), [thr] "s"(thr), [minrun] "s"(minrun)           \
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
@@ -384,11 +473,12 @@ __device__ __forceinline__ uint32_t orbit_run(uint32_t iterations, T &re, T &im,
         const uint64_t sq_bits = fr_bits_of(squared);
         const uint64_t lim2 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sq_bits) |
                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sq_bits >> 32)) << 32);
-        asm volatile(FR_ORBIT_ASM("f64") FR_ORBIT_OPERANDS);
+        asm volatile(FR_ORBIT_ASM("f64", "v_mov_b64") FR_ORBIT_OPERANDS);
     } else {
         const uint32_t lim2 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, squared));
-        asm volatile(FR_ORBIT_ASM("f32") FR_ORBIT_OPERANDS);
+        asm volatile(FR_ORBIT_ASM("f32", "v_mov_b32") FR_ORBIT_OPERANDS);
     }
+    (void)re1, (void)im1, (void)r21, (void)i21, (void)sspec;
     completed = si;
     return it;
 }
@@ -397,11 +487,11 @@ __device__ __forceinline__ uint32_t orbit_run(uint32_t iterations, T &re, T &im,
  * result = the escape index (== iterations on exhaustion). */
 template <typename T>
 __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T cre, T cim, T squared,
-                                          T &r2, T &i2) {
+                                          T &r2, T &i2, uint32_t spec_quiet = 0u) {
     r2 = re * re;
     i2 = im * im;
     uint32_t completed;
-    return orbit_run<T>(iterations, re, im, cre, cim, squared, r2, i2, EpisodeCtl{0, 0}, completed);
+    return orbit_run<T>(iterations, re, im, cre, cim, squared, r2, i2, EpisodeCtl{0, 0}, completed, spec_quiet);
 }
 
 /* ---- orbit loop, scaled form ------------------------------------------------------------------
@@ -632,23 +722,6 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
               FR_ORBIT_RECORD("A", "0") FR_ORBIT_RECORD("B", "1"), CYC_F, CYC_S, CYC_H, "", "", FR_SC_NOSPEC_ENTRY, "")
 #define FR_SC_ASM_M4(SFX) FR_SC_ASM_M4_(SFX, "", "", "", "", "", FR_SC_NOSPEC_ENTRY, "")
 #define FR_SC_ASM_M2(SFX) FR_SC_ASM_M2_(SFX, "", "", "")
-/* M = 4 with speculative blocks of FR_SPEC_M iterations (see FR_SC_SPEC_BODY) */
-#ifndef FR_SPEC_M
-#define FR_SPEC_M 16
-#endif
-#if FR_SPEC_M == 8
-#define FR_SPEC_MSTR "8"
-#define FR_SC_SPEC_REST(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S) FR_SC_IT_R(SFX, S, S)
-#elif FR_SPEC_M == 16
-#define FR_SPEC_MSTR "16"
-#define FR_SC_SPEC_REST(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S)
-#elif FR_SPEC_M == 32
-#define FR_SPEC_MSTR "32"
-#define FR_SC_SPEC_REST(SFX, S) \
-    FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R5(SFX, S) FR_SC_IT_R(SFX, S, S)
-#else
-#error "FR_SPEC_M must be 8, 16 or 32"
-#endif
 #define FR_SC_ASM_M4_SPEC(SFX, MOV)                                                                 \
     FR_SC_ASM_M4_(SFX, "", "", "", "s_mov_b32 %[sspec], %[specq]\n", FR_SC_SPEC_ARM, FR_SC_SPEC_ENTRY(FR_SPEC_MSTR), \
                   FR_SC_SPEC_BODY(SFX, MOV, FR_SPEC_MSTR, FR_SC_SPEC_REST))
@@ -792,7 +865,7 @@ __device__ __forceinline__ uint32_t orbit_auto(uint32_t loop_mode, uint32_t iter
             return orbit_scaled<T, 2>(iterations, re, im, cre, cim, squared, skip_t, r2, i2);
         }
     }
-    return orbit<T>(iterations, re, im, cre, cim, squared, r2, i2);
+    return orbit<T>(iterations, re, im, cre, cim, squared, r2, i2, spec_quiet);
 }
 
 /* coord_to_space — calc/src/lib.rs:182-184 */
@@ -2229,7 +2302,7 @@ __device__ __forceinline__ void refill_patch(const fr_kparams &p, const fr_kout 
         uint32_t it = 0, completed = 0, saved_index = 0xFFFFFFFFu;
         if (busy) {
             if constexpr (FORM == 0)
-                it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed);
+                it = orbit_run<T>(n, a0, a1, c0, c1, squared, a2, a3, ctl, completed, p.loop_spec);
             else
                 it = orbit_scaled_run<T, FORM, CYC>(n, a0, a1, a2, a3, c0, c1, squared, skip_t, ctl, completed, &xs, &ys,
                                                     &saved_index, p.loop_spec);

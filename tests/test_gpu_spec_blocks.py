@@ -69,6 +69,28 @@ def test_julia_views(fr):
     check(fr, O.cli_config(256, 160, O.JULIA, iterations=900, julia_set=(0.285, 0.01)), tiles=(0, 11, 13))
 
 
+@pytest.mark.parametrize("c", [(-1.0, 0.0), (0.0, 1.0), (0.25, 0.0), (-0.75, 0.0)])
+def test_named_julia_sets_run_the_unscaled_loop_speculatively(fr, c):
+    """A Julia constant with a zero component is outside the scaled form's proof (every wave takes the loop as written,
+    FR_ORBIT_ASM): its interior runs in speculative blocks of 7-instruction iterations, its boundary escapes late."""
+    check(fr, O.cli_config(256, 160, O.JULIA, iterations=1200, julia_set=c), modes=(-1, 0, 5), tiles=(0, 9, 13))
+
+
+def test_unscaled_loop_forced_and_small_limits(fr):
+    """Selector 0 on a deep boundary view; limits that leave no room for skipped checks (4.5: limit^2 / 8 just above the
+    view's largest |c|; 3.9: below 16, no speculation) at caps with every remainder modulo 16."""
+    check(fr, O.cli_config(200, 120, iterations=2500, **SEAHORSE), modes=(0,), tiles=(0, 9))
+    for limit in (4.5, 3.9, 10.0, 150.0):
+        for iterations in (333, 1030):
+            check(fr, O.cli_config(200, 120, iterations=iterations, limit=limit), modes=(-1, 5), tiles=(0, 9))
+
+
+def test_the_real_axis_strip(fr):
+    """Mandelbrot rows through im = 0 are unscalable (a zero component of c): those strips run the unscaled loop inside a
+    launch planned for the scaled one — both speculate; odd height puts the axis on a pixel row."""
+    check(fr, O.cli_config(300, 201, iterations=900), tiles=(0, 9, 13))
+
+
 def test_a_start_that_overflows_inside_a_block(fr):
     """limit 2^400: an orbit past it overflows to +inf and then NaN within a few iterations — inside one speculative block;
     the end test is `NOT (T >= dist)`, true for NaN, so the block is rolled back and the escape found at its iteration.
@@ -76,6 +98,10 @@ def test_a_start_that_overflows_inside_a_block(fr):
     check(fr, O.cli_config(160, 96, iterations=120, limit=2.0 ** 400, scale=(1e-3, 1e-3), pos=(0.0, 0.0)),
           modes=(-1, 5, 0), tiles=(0, 13), precisions=("f64",))
     check(fr, O.cli_config(160, 96, iterations=400, limit=2.0 ** 400), modes=(-1, 5), tiles=(0, 13), precisions=("f64",))
+    # limit 2^500 (unscaled loop; limit^2 = 2^1000 is the largest that speculates) and 2^501 (does not)
+    for limit in (2.0 ** 500, 2.0 ** 501):
+        check(fr, O.cli_config(160, 96, iterations=200, limit=limit, scale=(1e-140, 1e-140), pos=(0.0, 0.0)),
+              modes=(-1, 5), tiles=(0,), precisions=("f64",))
 
 
 def test_same_device_bytes_with_and_without_speculation_at_4k(fr):

@@ -33,6 +33,7 @@ CASES = {
     "c4f64": ("julia", size, 4096, "f64"),
     "filled": ("filled_julia", size, 1024, "f64"),
     "gui4k": ("default", 0, 1024, "f64"),  # 3840 x 2160
+    "basilica0": ("filled_julia", size, 1024, "f64"),  # c = -1 + 0i EXACTLY: the unscaled loop (a zero component)
 }
 
 
@@ -41,6 +42,8 @@ def view(name):
     cfg = bench.make_config(fr, v, edge or 3840, its)
     if not edge:
         cfg.height = 2160
+    if name == "basilica0":
+        cfg.julia_set.im = 0.0
     return cfg, fr.Precision.F32 if prec == "f32" else fr.Precision.F64
 
 
