@@ -723,12 +723,17 @@ struct Decision {
     int choice;
     bool one_band;
     uint32_t strip_tiles;
+    bool no_spec; /* nothing in the view stays long enough for a speculative block to pay (plan_loop's loop_spec is cleared) */
 };
 
 static Decision decide_from_sample(const double st[7], uint64_t tiles, const fr_kparams &p, int precision, bool two_pass_ok) {
     const double lanes = 64.0 * st[2];
     const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes, handed = st[4] / lanes;
-    Decision d{2, false, 0u};
+    /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY) pay where waves stay quiet for dozens of iterations.  A view
+     * in which no sampled pixel reaches the cap and orbits are short on average has no such waves — C4's dust: mean 44, and
+     * the first pass's speculative form costs it 1.5 % in set-up per tile that stays an episode — so it is rendered by the
+     * kernels without them.  (Long orbits that all escape in the end — filaments at high caps — still gain: mean >= 96.) */
+    Decision d{2, false, 0u, capped < 0.0005 && mean < 96.0};
     if (tiles >= kMidRuleTiles) {
         if (capped >= 0.10 && waste < 0.01)
             d.choice = 0; /* long orbits dominate and tiles stay full: the strip kernel's ground */
@@ -789,8 +794,9 @@ void Ctx::post_sample(int idx, hipStream_t stream) {
 }
 
 static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, int precision, const Opts &o, hipStream_t stream,
-                         bool allow_async, bool *one_band, uint32_t *strip_tiles, int *pending) {
+                         bool allow_async, bool *one_band, uint32_t *strip_tiles, int *pending, bool *no_spec) {
     *one_band = false;
+    *no_spec = false;
     *strip_tiles = 0;
     *pending = -1;
     if (o.tile != 0 || !g_dispatch_sampling.load()) return -1;
@@ -816,12 +822,13 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
                     v.state = 2, v.two_pass = -1;
                 } else {
                     const Decision d = decide_from_sample(st, tiles, p, precision, two_pass_ok);
-                    v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles;
+                    v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles, v.no_spec = d.no_spec;
                     v.lane_fraction = st[0] / st[1];
                 }
             }
             *one_band = v.one_band;
             *strip_tiles = v.strip_tiles;
+            *no_spec = v.no_spec;
             return v.two_pass;
         }
         /* a view not seen before.  No sample of either kind while the caller's stream is being captured */
@@ -852,8 +859,10 @@ static int choose_kernel(Ctx &ctx, const fr_config *cfg, const fr_kparams &p, in
     }
     const Decision d = decide_from_sample(st, tiles, p, precision, two_pass_ok);
     v.state = 2, v.two_pass = d.choice, v.one_band = d.one_band, v.strip_tiles = d.strip_tiles, v.lane_fraction = st[0] / st[1];
+    v.no_spec = d.no_spec;
     *one_band = d.one_band;
     *strip_tiles = d.strip_tiles;
+    *no_spec = d.no_spec;
     return d.choice;
 }
 
@@ -867,11 +876,12 @@ void decide_kernel(Ctx &ctx, const fr_config *cfg, int precision, uint32_t y0, u
     p.block_rows = p.nrows;
     p.y_stride = 0;
     plan_loop(cfg, precision, o, p);
-    bool one_band = false;
+    bool one_band = false, no_spec = false;
     uint32_t strip_tiles = 0;
     int pending = -1;
-    o.kernel_hint = choose_kernel(ctx, cfg, p, precision, o, stream, allow_async, &one_band, &strip_tiles, &pending);
+    o.kernel_hint = choose_kernel(ctx, cfg, p, precision, o, stream, allow_async, &one_band, &strip_tiles, &pending, &no_spec);
     o.one_band = one_band;
+    o.no_spec = no_spec;
     o.strip_tiles = strip_tiles;
     o.pending_sample = pending;
 }
@@ -888,11 +898,12 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
     const bool escape_algo = cfg->algo == FR_ALGO_MANDELBROT || cfg->algo == FR_ALGO_JULIA;
     PaletteSlot *slot = nullptr;
     const bool want_palette = !cfg->smooth && escape_algo && o.palette && cfg->iterations < FR_MAX_PALETTE_ENTRIES && o.tile <= 16;
-    bool one_band = o.one_band;
+    bool one_band = o.one_band, no_spec = o.no_spec;
     uint32_t strip_tiles = o.strip_tiles;
     int pending = -1;
     const int hint = o.kernel_hint != -2 ? o.kernel_hint
-                                         : choose_kernel(ctx, cfg, p, precision, o, stream, true, &one_band, &strip_tiles, &pending);
+                                         : choose_kernel(ctx, cfg, p, precision, o, stream, true, &one_band, &strip_tiles, &pending, &no_spec);
+    if (no_spec) p.loop_spec = 0; /* the view's statistics: nothing stays (decide_from_sample) */
     struct SampleGuard { /* whatever happens below, a slot that was promised a sample gets it (or is freed) */
         Ctx &ctx;
         int idx;

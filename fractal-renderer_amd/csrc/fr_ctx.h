@@ -51,6 +51,7 @@ struct Opts {
      * one-strip-per-workgroup flag */
     int kernel_hint = -2;
     bool one_band = false;
+    bool no_spec = false; /* with kernel_hint >= 0: the view's statistics say nothing stays — no speculative blocks (fr_api.hip: decide_from_sample) */
     uint32_t strip_tiles = 0; /* with kernel_hint >= 0: the strip length the view's statistics call for (0 = by launch size) */
     /* a non-blocking view sample the caller still has to post BEHIND its render (Ctx::post_sample): slot index, -1 none */
     int pending_sample = -1;
@@ -114,6 +115,7 @@ struct Ctx {
         int state = 0; /* 0 free, 1 a sample is (about to be) in flight, 2 decided */
         int two_pass = -1; /* -1 no opinion, 0 strips, 1 two passes, 2 the first pass alone */
         bool one_band = false;
+        bool no_spec = false;
         uint32_t strip_tiles = 0;
         double lane_fraction = 0.0;
         fr_kparams grid; /* state 1: what the sample is launched with */

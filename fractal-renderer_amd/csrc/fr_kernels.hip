@@ -332,7 +332,7 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
 #define FR_ORBIT_RECORD(TAG, OFFSET) FR_ORBIT_RECORD_(TAG, OFFSET, "")
 /* the unscaled loop's form: a lane that escapes re-arms the quiet stretch before the wave may speculate (FR_ORBIT_ASM) */
 #define FR_ORBIT_RECORD_A(TAG, OFFSET)             \
-    FR_ORBIT_RECORD_(TAG, OFFSET, "s_add_u32 %[sspec], %[si], %[specq]\n" "s_cselect_b32 %[sspec], -1, %[sspec]\n")
+    FR_ORBIT_RECORD_(TAG, OFFSET, "s_add_u32 %[sspec], %[si], %[specq]\n" "s_cselect_b32 %[sspec], -1, %[sspec]\n" "s_min_u32 %[sspec], %[sspec], %[n]\n")
 
 /* length of a speculative block (FR_ORBIT_ASM, FR_SC_SPEC_BODY, FR_FB_SPEC_LOOP): FR_SPEC_M iterations */
 #ifndef FR_SPEC_M
@@ -383,7 +383,7 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
     "s_mov_b64 %[sorig], exec\n"                                                   \
     "v_mov_b32 %[it], %[n]\n"                                                      \
     "s_mov_b32 %[si], 0\n"                                                         \
-    "s_mov_b32 %[sspec], %[specq]\n"                                               \
+    "s_min_u32 %[sspec], %[specq], %[n]\n"                                         \
     "s_cbranch_execz .Ldone_%=\n"                                                  \
     "s_and_b32 %[nrem], %[n], 3\n"                                                 \
     "s_cbranch_scc0 .Lmainentry_%=\n"                                              \
@@ -396,14 +396,14 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
     "s_cbranch_scc0 .Ldone_%=\n"                                                   \
     ".Lmain_%=:\n" FR_ORBIT_STEP(SFX, "A") FR_ORBIT_STEP(SFX, "B") FR_ORBIT_STEP(SFX, "C") FR_ORBIT_STEP(SFX, "D") \
     "s_add_u32 %[si], %[si], 4\n"                                                  \
+    "s_cmp_lt_u32 %[si], %[sspec]\n"  /* the one bound: min(n, end of the quiet stretch) */ \
+    "s_cbranch_scc1 .Lmain_%=\n"                                                   \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc0 .Ldone_%=\n"                                                   \
-    "s_cmp_lt_u32 %[si], %[sspec]\n"                                               \
-    "s_cbranch_scc1 .Lmain_%=\n"                                                   \
     "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
     "s_cmp_ge_u32 %[stmp], " FR_SPEC_MSTR "\n"                                     \
     "s_cbranch_scc1 .Lspec_%=\n"                                                   \
-    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_mov_b32 %[sspec], %[n]\n"                                                   \
     "s_branch .Lmain_%=\n"                                                         \
     ".Lspec_%=:\n" FR_ORBIT_IT_R(SFX, "", "1") FR_ORBIT_SPEC_REST(SFX, "1")        \
     "v_add_" SFX " %[t], %[r21], %[i21]\n"                                         \
@@ -424,7 +424,7 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
     "s_branch .Lspecout_%=\n"                                                      \
     ".LexA_%=:\n" FR_ORBIT_SPEC_MOVS(MOV)                                          \
     ".Lspecout_%=:\n"                                                              \
-    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_mov_b32 %[sspec], %[n]\n"                                                   \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc1 .Lmain_%=\n"                                                   \
     "s_branch .Ldone_%=\n"                                                         \
@@ -434,6 +434,7 @@ __device__ __forceinline__ void colour_pixel(const ColourConsts &c, T re, T im, 
     "s_min_u32 %[specq], %[specq], 0x8000\n"                                       \
     "s_add_u32 %[sspec], %[si], %[specq]\n"                                        \
     "s_cselect_b32 %[sspec], -1, %[sspec]\n"                                       \
+    "s_min_u32 %[sspec], %[sspec], %[n]\n"                                         \
     "s_branch .Lmain_%=\n"                                                         \
     FR_ORBIT_RECORD_A("R", "0") FR_ORBIT_RECORD_A("A", "0") FR_ORBIT_RECORD_A("B", "1") \
     FR_ORBIT_RECORD_A("C", "2") FR_ORBIT_RECORD_A("D", "3")                         \
@@ -465,7 +466,7 @@ __device__ __forceinline__ uint32_t orbit_run(uint32_t iterations, T &re, T &im,
     : [re] "+v"(re), [im] "+v"(im), [r2] "+v"(r2), [i2] "+v"(i2), [it] "=&v"(it), [t] "=&v"(t), [x] "=&v"(x),      \
       [sorig] "=&s"(sorig), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [si] "=&s"(si), [stmp] "=&s"(stmp),        \
       [nrem] "=&s"(nrem), [scnt] "=&s"(scnt), [re1] "=&v"(re1), [im1] "=&v"(im1), [r21] "=&v"(r21),                \
-      [i21] "=&v"(i21), [sspec] "=&s"(sspec), [specq] "+s"(specq)                                                  \
+      [i21] "=&v"(i21), [sspec] "=&s"(sspec), [specq] "+&s"(specq)                                                 \
     : [cre] "v"(cre), [cim] "v"(cim), [lim2] "s"(lim2), [n] "s"(n), [thr] "s"(thr), [minrun] "s"(minrun)           \
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
@@ -553,24 +554,27 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
  *     above from there, which finds the escape at its exact iteration; speculation stays off for the next %[specq]
  *     iterations.  A lane merely in transit at the block's end (above T, not yet above the limit) takes the same road.
  * Lanes that have escaped are not in EXEC and keep their final state in set 0, where the checked code left it. */
+/* the checked loop's own bound is %[sspec] = min(n, where the quiet stretch ends): no scalar instruction more per block
+ * than without speculation; what the bound meant is sorted out when it is reached */
 #define FR_SC_SPEC_ENTRY(MSTR)                                                     \
-    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
-    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
     "s_cmp_lt_u32 %[si], %[sspec]\n"                                               \
     "s_cbranch_scc1 .Lfast_%=\n"                                                   \
+    "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
+    "s_cbranch_scc0 .Ldone_%=\n"                                                   \
     "s_sub_u32 %[stmp], %[n], %[si]\n"                                             \
     "s_cmp_ge_u32 %[stmp], " MSTR "\n"                                             \
     "s_cbranch_scc1 .Lspec_%=\n"                                                   \
-    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_mov_b32 %[sspec], %[n]\n"                                                   \
     "s_branch .Lfast_%=\n"
 #define FR_SC_NOSPEC_ENTRY                                                         \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc1 .Lfast_%=\n"                                                   \
     "s_branch .Ldone_%=\n"
-/* sspec = si + specq, saturating: the iteration count from which the wave may speculate (again) */
+/* sspec = min(n, si + specq), saturating: the iteration count from which the wave may speculate (again), or the cap */
 #define FR_SC_SPEC_ARM                                                             \
     "s_add_u32 %[sspec], %[si], %[specq]\n"                                        \
-    "s_cselect_b32 %[sspec], -1, %[sspec]\n"
+    "s_cselect_b32 %[sspec], -1, %[sspec]\n"                                       \
+    "s_min_u32 %[sspec], %[sspec], %[n]\n"
 #define FR_SC_SPEC_BODY(SFX, MOV, MSTR, REST)                                      \
     ".Lspec_%=:\n" FR_SC_IT_R(SFX, "", "1") REST(SFX, "1")                         \
     "v_add_" SFX " %[t], %[A1], %[B1]\n"                                           \
@@ -592,7 +596,7 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
     ".LexA_%=:\n"                                                                  \
     MOV " %[X], %[X1]\n" MOV " %[Y], %[Y1]\n" MOV " %[A], %[A1]\n" MOV " %[B], %[B1]\n" \
     ".Lspecout_%=:\n"                                                              \
-    "s_mov_b32 %[sspec], -1\n"                                                     \
+    "s_mov_b32 %[sspec], %[n]\n"                                                   \
     "s_cmp_lt_u32 %[si], %[n]\n"                                                   \
     "s_cbranch_scc1 .Lfast_%=\n"                                                   \
     "s_branch .Ldone_%=\n"                                                         \
@@ -723,7 +727,7 @@ __device__ __forceinline__ uint32_t orbit(uint32_t iterations, T &re, T &im, T c
 #define FR_SC_ASM_M4(SFX) FR_SC_ASM_M4_(SFX, "", "", "", "", "", FR_SC_NOSPEC_ENTRY, "")
 #define FR_SC_ASM_M2(SFX) FR_SC_ASM_M2_(SFX, "", "", "")
 #define FR_SC_ASM_M4_SPEC(SFX, MOV)                                                                 \
-    FR_SC_ASM_M4_(SFX, "", "", "", "s_mov_b32 %[sspec], %[specq]\n", FR_SC_SPEC_ARM, FR_SC_SPEC_ENTRY(FR_SPEC_MSTR), \
+    FR_SC_ASM_M4_(SFX, "", "", "", "s_min_u32 %[sspec], %[specq], %[n]\n", FR_SC_SPEC_ARM, FR_SC_SPEC_ENTRY(FR_SPEC_MSTR), \
                   FR_SC_SPEC_BODY(SFX, MOV, FR_SPEC_MSTR, FR_SC_SPEC_REST))
 #define FR_SC_CYC_HANDLERS(MOV) \
     FR_SC_CYC_HANDLER("F") FR_SC_CYC_HANDLER("S") FR_SC_CYC_SAVE(MOV, "F") FR_SC_CYC_SAVE(MOV, "S")
@@ -789,7 +793,7 @@ __device__ __forceinline__ uint32_t orbit_scaled_run(uint32_t iterations, T &X, 
 #define FR_SC_OPERANDS : FR_SC_OUTPUTS : FR_SC_INPUTS : "vcc", "scc"
 #define FR_SC_OPERANDS_SPEC                                                                                     \
     : FR_SC_OUTPUTS, [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [sspec] "=&s"(sspec),      \
-      [specq] "+s"(specq)                                                                                       \
+      [specq] "+&s"(specq)                                                                                      \
     : FR_SC_INPUTS                                                                                              \
     : "vcc", "scc"
 #define FR_SC_OPERANDS_CYC                                                                                      \
@@ -1561,57 +1565,68 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
     "s_mov_b64 exec, %[sorig]\n"
 
 /* M = 4: the same two loops with the speculative long blocks of the strip kernel's loop (FR_SC_SPEC_BODY has the argument):
- * after %[specq] blocks in which no lane froze, the wave runs FR_SPEC_M iterations at a time with one `NOT (T >= dist)` test
- * at their end, the first iteration writing to the second register set so that the block's start state survives; a failed
- * test throws the block away and the checked blocks above run from its start state — they freeze the same lanes at the same
- * iterations with the same counts as if there had been no speculation.  %[k] counts blocks of four: a speculative block is
- * FR_SPEC_M / 4 of them.  (96 + 2) / 16 = 6.125 instructions per iteration (f32, counting per lane: 6.19) against 6.5 (6.75). */
-#define FR_FB_SPEC_ARM                                 \
-    "s_sub_u32 %[kspec], %[k], %[specq]\n"             \
-    "s_cselect_b32 %[kspec], 0, %[kspec]\n"
-#define FR_FB_SPEC_TRY(KB1, LOOP)                      \
-    "s_cmp_gt_u32 %[k], %[kspec]\n"                    \
-    "s_cbranch_scc1 " LOOP "\n"                        \
-    "s_cmp_lt_u32 %[k], " KB1 "\n"                     \
-    "s_cbranch_scc1 " LOOP "\n"
+ * after a STRETCH of %[specq] blocks in which no lane froze, the wave runs FR_SPEC_M iterations at a time with one
+ * `NOT (T >= dist)` test at their end, the first iteration writing to the second register set so that the block's start state
+ * survives; a failed test throws the block away and the checked blocks run from its start state — they freeze the same lanes
+ * at the same iterations with the same counts as if there had been no speculation.  (96 + 2) / 16 = 6.125 instructions per
+ * iteration (f32, counting per lane: 6.19) against 6.5 (6.75).
+ *
+ * Counters, in blocks of four iterations: %[k] = blocks left in the current stretch - 1 (the checked loop's own counter: it
+ * costs what the loop without speculation costs — C4, where nothing ever stays, was 2.5 % slower with a separate
+ * comparison per block), %[kend] = blocks left after the stretch; remaining = k + 1 + kend.  A stretch ends by borrow:
+ * nothing left -> done; EXEC as it was when the stretch began -> quiet: speculate while kend >= KB; else a new stretch.
+ * A speculative block is KB = FR_SPEC_M / 4 blocks of kend. */
+/* begin a stretch over the remaining R = %[kend] blocks (R >= 1): k = min(R, specq) - 1, kend = R - k - 1, EXEC remembered */
+#define FR_FB_SPEC_STRETCH                             \
+    "s_min_u32 %[k], %[kend], %[specq]\n"              \
+    "s_sub_u32 %[kend], %[kend], %[k]\n"               \
+    "s_sub_u32 %[k], %[k], 1\n"                        \
+    "s_mov_b64 %[squiet], exec\n"
 #define FR_FB_SPEC_MOVS(MOV) MOV " %[X], %[X1]\n" MOV " %[Y], %[Y1]\n" MOV " %[A], %[A1]\n" MOV " %[B], %[B1]\n"
-/* the speculative loop; COUNT = what a successful block does for the per-lane count ("" in the handler form);
- * KB = FR_SPEC_M / 4, KB1 = KB - 1 */
-#define FR_FB_SPEC_LOOP(SFX, MOV, REST, KB, KB1, COUNT, LOOP, DONE)     \
+/* the end of a stretch and the speculative loop behind it; COUNT = what a successful block does for the per-lane count
+ * ("" in the handler form); LOOP = the checked loop's head, DONE = the exit */
+#define FR_FB_SPEC_EVENT(SFX, MOV, REST, KB, COUNT, LOOP, DONE)  \
+    "s_cmp_eq_u32 %[kend], 0\n"                               \
+    "s_cbranch_scc1 " DONE "\n"                               \
+    "s_cmp_eq_u64 %[squiet], exec\n"                          \
+    "s_cbranch_scc0 .Lfnew_%=\n"                              \
+    "s_cmp_lt_u32 %[kend], " KB "\n"                          \
+    "s_cbranch_scc1 .Lfnew_%=\n"                              \
     ".Lfsp_%=:\n" FR_SC_IT_R(SFX, "", "1") REST(SFX, "1")     \
     "v_add_" SFX " %[t], %[A1], %[B1]\n"                      \
     "v_cmp_nge_" SFX " vcc, %[t4lim], %[t]\n"                 \
     "s_cbranch_vccnz .LfrbA_%=\n"                             \
     COUNT                                                     \
-    "s_sub_u32 %[k], %[k], " KB "\n"                          \
-    "s_cbranch_scc1 .LfexAd_%=\n"                             \
-    "s_cmp_lt_u32 %[k], " KB1 "\n"                            \
+    "s_sub_u32 %[kend], %[kend], " KB "\n"                    \
+    "s_cmp_lt_u32 %[kend], " KB "\n"                          \
     "s_cbranch_scc1 .LfexA_%=\n"                              \
     FR_SC_IT_R(SFX, "1", "") REST(SFX, "")                    \
     "v_add_" SFX " %[t], %[A], %[B]\n"                        \
     "v_cmp_nge_" SFX " vcc, %[t4lim], %[t]\n"                 \
     "s_cbranch_vccnz .LfrbB_%=\n"                             \
     COUNT                                                     \
-    "s_sub_u32 %[k], %[k], " KB "\n"                          \
-    "s_cbranch_scc1 " DONE "\n"                               \
-    "s_cmp_lt_u32 %[k], " KB1 "\n"                            \
-    "s_cbranch_scc1 " LOOP "\n"                               \
-    "s_branch .Lfsp_%=\n"                                     \
-    ".LfexAd_%=:\n" FR_FB_SPEC_MOVS(MOV)                      \
-    "s_branch " DONE "\n"                                     \
+    "s_sub_u32 %[kend], %[kend], " KB "\n"                    \
+    "s_cmp_lt_u32 %[kend], " KB "\n"                          \
+    "s_cbranch_scc0 .Lfsp_%=\n"                               \
+    "s_branch .Lfrest_%=\n"                                   \
     ".LfexA_%=:\n" FR_FB_SPEC_MOVS(MOV)                       \
-    "s_branch " LOOP "\n"                                     \
+    ".Lfrest_%=:\n"  /* fewer than KB blocks left: the rest runs checked (or nothing is left) */ \
+    "s_cmp_eq_u32 %[kend], 0\n"                               \
+    "s_cbranch_scc1 " DONE "\n"                               \
+    "s_branch .Lfnew_%=\n"                                    \
     ".LfrbB_%=:\n" FR_FB_SPEC_MOVS(MOV)                       \
     ".LfrbA_%=:\n"                                            \
     "s_lshl_b32 %[specq], %[specq], 1\n"                      \
     "s_min_u32 %[specq], %[specq], 0x2000\n"                  \
-    FR_FB_SPEC_ARM                                            \
+    ".Lfnew_%=:\n" FR_FB_SPEC_STRETCH                         \
     "s_branch " LOOP "\n"
 
-#define FR_FB_SPEC_ASM(SFX, MOV, BLOCK_ITS, MSHIFT, REST, KB, KB1) \
+/* handler form (f64): %[n0] = the number of blocks to run (>= 1) */
+#define FR_FB_SPEC_ASM(SFX, MOV, BLOCK_ITS, MSHIFT, REST, KB) \
     "s_mov_b64 %[sorig], exec\n"                       \
     "s_mov_b64 exec, %[mask]\n"                        \
-    FR_FB_SPEC_ARM                                     \
+    "s_mov_b32 %[kend], %[n0]\n"                       \
+    FR_FB_SPEC_STRETCH                                 \
     ".Lfb_%=:\n" BLOCK_ITS                             \
     "v_add_" SFX " %[t], %[A], %[B]\n"                 \
     "s_mov_b64 %[sprev], exec\n"                       \
@@ -1620,11 +1635,11 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
     "s_cbranch_scc1 .Lfbr_%=\n"                        \
     ".Lfbc_%=:\n"                                      \
     "s_sub_u32 %[k], %[k], 1\n"                        \
-    "s_cbranch_scc1 .Lfbd_%=\n"                        \
-    FR_FB_SPEC_TRY(KB1, ".Lfb_%=")                     \
-    FR_FB_SPEC_LOOP(SFX, MOV, REST, KB, KB1, "", ".Lfb_%=", ".Lfbd_%=") \
-    ".Lfbr_%=:\n" FR_FB_SPEC_ARM                       \
-    "s_sub_u32 %[stmp], %[n0], %[k]\n"                 \
+    "s_cbranch_scc0 .Lfb_%=\n"                         \
+    FR_FB_SPEC_EVENT(SFX, MOV, REST, KB, "", ".Lfb_%=", ".Lfbd_%=") \
+    ".Lfbr_%=:\n"  /* blocks run so far, this one included = n0 - (k + kend) */ \
+    "s_add_u32 %[stmp], %[k], %[kend]\n"               \
+    "s_sub_u32 %[stmp], %[n0], %[stmp]\n"              \
     "s_lshl_b32 %[stmp], %[stmp], " MSHIFT "\n"        \
     "s_add_u32 %[stmp], %[stmp], %[base]\n"            \
     "s_mov_b64 %[sprev], exec\n"                       \
@@ -1636,65 +1651,57 @@ __device__ __forceinline__ typename UBits<T>::type uniform_bits(T v) {
     "s_mov_b64 %[srun], exec\n"                        \
     "s_mov_b64 exec, %[sorig]\n"
 
-/* per-lane count: a lane that freezes re-arms the quiet stretch through the EXEC comparison the handler form gets for free;
- * here it costs two scalar instructions a block (s_mov + s_cmp on EXEC) */
-#define FR_FBC_SPEC_ASM(SFX, MOV, BLOCK_ITS, STEP, REST, KB, KB1, SPECSTEP) \
+/* per-lane count (f32): %[n0] = the number of blocks to run (>= 1) */
+#define FR_FBC_SPEC_ASM(SFX, MOV, BLOCK_ITS, STEP, REST, KB, SPECSTEP) \
     "s_mov_b64 %[sorig], exec\n"                       \
     "s_mov_b64 exec, %[mask]\n"                        \
-    FR_FB_SPEC_ARM                                     \
+    "s_mov_b32 %[kend], %[n0]\n"                       \
+    FR_FB_SPEC_STRETCH                                 \
     ".Lfc_%=:\n" BLOCK_ITS                             \
     "v_add_" SFX " %[t], %[A], %[B]\n"                 \
     "v_add_f32 %[cnt], %[cnt], " STEP "\n"             \
-    "s_mov_b64 %[sprev], exec\n"                       \
     "v_cmpx_nlt_" SFX " %[t4lim], %[t]\n"              \
     "s_cbranch_execz .Lfcd_%=\n"                       \
-    "s_cmp_eq_u64 %[sprev], exec\n"                    \
-    "s_cbranch_scc0 .Lfcr_%=\n"                        \
-    "s_sub_u32 %[k], %[k], 1\n"                        \
-    "s_cbranch_scc1 .Lfcd_%=\n"                        \
-    FR_FB_SPEC_TRY(KB1, ".Lfc_%=")                     \
-    FR_FB_SPEC_LOOP(SFX, MOV, REST, KB, KB1, "v_add_f32 %[cnt], " SPECSTEP ", %[cnt]\n", ".Lfc_%=", ".Lfcd_%=") \
-    ".Lfcr_%=:\n" FR_FB_SPEC_ARM                       \
     "s_sub_u32 %[k], %[k], 1\n"                        \
     "s_cbranch_scc0 .Lfc_%=\n"                         \
+    FR_FB_SPEC_EVENT(SFX, MOV, REST, KB, "v_add_f32 %[cnt], " SPECSTEP ", %[cnt]\n", ".Lfc_%=", ".Lfcd_%=") \
     ".Lfcd_%=:\n"                                      \
     "s_mov_b64 %[srun], exec\n"                        \
     "s_mov_b64 exec, %[sorig]\n"
 
 #if FR_SPEC_M == 8
 #define FR_SPEC_KB "2"
-#define FR_SPEC_KB1 "1"
 #define FR_SPEC_STEP "0x41000000" /* 8.0f: a literal, VOP2 takes it as src0 */
 #elif FR_SPEC_M == 16
 #define FR_SPEC_KB "4"
-#define FR_SPEC_KB1 "3"
 #define FR_SPEC_STEP "0x41800000" /* 16.0f: a literal, VOP2 takes it as src0 */
 #else
 #define FR_SPEC_KB "8"
-#define FR_SPEC_KB1 "7"
 #define FR_SPEC_STEP "0x42000000" /* 32.0f */
 #endif
 
-template <typename T, int M>
+template <typename T, int M, bool SPEC = false>
 __device__ __forceinline__ unsigned long long first_blocks(unsigned long long mask, uint32_t nblocks, uint32_t done_before, T &X, T &Y,
                                                            T &A, T &B, T &t, float &cnt, T c2re, T c2im,
                                                            typename UBits<T>::type t4lim, uint32_t spec_quiet_blocks = 0u) {
     T q;
     T X1, Y1, A1, B1; /* M == 4: the second register set of the speculative blocks */
-    uint32_t kspec;
     uint32_t specq = __builtin_amdgcn_readfirstlane(spec_quiet_blocks ? spec_quiet_blocks : 0xFFFFFFFFu); /* 0 = never; doubles with every block thrown away */
     unsigned long long sorig, srun, sprev, sdiff;
-    (void)X1, (void)Y1, (void)A1, (void)B1, (void)kspec, (void)specq;
-#define FR_FB_SPEC_OUT , [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [kspec] "=&s"(kspec), [specq] "+s"(specq)
+    (void)X1, (void)Y1, (void)A1, (void)B1, (void)specq;
     if constexpr (sizeof(T) == 4) {
         uint32_t kc = __builtin_amdgcn_readfirstlane(nblocks) - 1u;
         (void)done_before, (void)sdiff;
-        if constexpr (M == 4) {
+        if constexpr (M == 4 && SPEC) {
+            const uint32_t nb = kc + 1u; /* the blocks to run; kc becomes the stretch counter */
+            uint32_t kend;
+            unsigned long long squiet;
             asm volatile(FR_FBC_SPEC_ASM("f32", "v_mov_b32", FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32") FR_SC_IT("f32"), "4.0",
-                                         FR_SC_SPEC_REST, FR_SPEC_KB, FR_SPEC_KB1, FR_SPEC_STEP)
+                                         FR_SC_SPEC_REST, FR_SPEC_KB, FR_SPEC_STEP)
                          : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),
-                           [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [k] "+s"(kc) FR_FB_SPEC_OUT
-                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask)
+                           [sorig] "=&s"(sorig), [srun] "=&s"(srun), [squiet] "=&s"(squiet), [k] "=&s"(kc), [kend] "=&s"(kend),
+                           [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [specq] "+&s"(specq)
+                         : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(nb)
                          : "vcc", "scc");
             return srun;
         }
@@ -1719,14 +1726,21 @@ __device__ __forceinline__ unsigned long long first_blocks(unsigned long long ma
     : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(n0), [base] "s"(base)   \
     : "vcc", "scc"
     if constexpr (sizeof(T) == 8) {
-        if constexpr (M == 4)
+        if constexpr (M == 4 && SPEC)
+        {
+            uint32_t kend; /* blocks left behind the current stretch; k becomes the stretch counter */
+            unsigned long long squiet;
             asm volatile(FR_FB_SPEC_ASM("f64", "v_mov_b64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "2",
-                                        FR_SC_SPEC_REST, FR_SPEC_KB, FR_SPEC_KB1)
+                                        FR_SC_SPEC_REST, FR_SPEC_KB)
                          : [X] "+v"(X), [Y] "+v"(Y), [A] "+v"(A), [B] "+v"(B), [t] "+v"(t), [cnt] "+v"(cnt), [q] "=&v"(q),
-                           [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [k] "+s"(k),
-                           [stmp] "=&s"(stmp) FR_FB_SPEC_OUT
+                           [sorig] "=&s"(sorig), [srun] "=&s"(srun), [sprev] "=&s"(sprev), [sdiff] "=&s"(sdiff), [k] "=&s"(k),
+                           [stmp] "=&s"(stmp), [squiet] "=&s"(squiet), [kend] "=&s"(kend),
+                           [X1] "=&v"(X1), [Y1] "=&v"(Y1), [A1] "=&v"(A1), [B1] "=&v"(B1), [specq] "+&s"(specq)
                          : [c2re] "v"(c2re), [c2im] "v"(c2im), [t4lim] "s"(t4lim), [mask] "s"(mask), [n0] "s"(n0), [base] "s"(base)
                          : "vcc", "scc");
+        }
+        else if constexpr (M == 4)
+            asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64") FR_SC_IT("f64"), "2") FR_FB_OPERANDS);
         else
             asm volatile(FR_FB_ASM("f64", FR_SC_IT("f64") FR_SC_IT("f64"), "1") FR_FB_OPERANDS);
     }
@@ -1898,7 +1912,7 @@ __device__ __forceinline__ typename UBits<T>::type bpermute_t(uint32_t byte_inde
     }
 }
 
-template <typename T, int M, int kStripTiles, int kBands>
+template <typename T, int M, int kStripTiles, int kBands, bool SPEC = false>
 __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, const fr_kout out) {
     __shared__ uint32_t s_palette[FR_MAX_PALETTE_ENTRIES]; /* smooth == false only; the log2 table stays in L2 (see v1) */
     const double *const s_tab = &g_log2_tab[0][0];
@@ -1965,11 +1979,6 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
     /* the asm path runs a whole first episode and up to 64 exact iterations without looking at the cap */
     const bool fast_tiles = k1 % (uint32_t)M == 0u && k1 + 64u <= cap;
     const uint32_t nblk1 = k1 / (uint32_t)M;
-    uint32_t spec_blocks; /* quiet blocks before a wave speculates in the later episodes (first_blocks); 0 = never */
-    {
-        FR_COLD_PARAMS(kp);
-        spec_blocks = kp->loop_spec / (uint32_t)M;
-    }
     /* the strip's tiles: `ntiles` lie (partly) inside the image, the first `nfull` of them with all 8 columns */
     const uint32_t cols_left = ncols - tile0 * 8u; /* > 0: the grid has no workgroup past the right edge */
     const uint32_t ntiles = (cols_left + 7u) / 8u < (uint32_t)kStripTiles ? (cols_left + 7u) / 8u : (uint32_t)kStripTiles;
@@ -2062,12 +2071,24 @@ __global__ __launch_bounds__(64) void escape_first_kernel(const fr_kparams p, co
                      * tried: C4's dense tiles thin out within an episode or two and idled through the longer ones) */
                     uint32_t len = k1;
                     bool first = st == 1u; /* the asm path has run the first episode */
+                    /* SPEC (the host launches this form when the plan allows speculation and the view's statistics, where
+                     * there are any, do not say that nothing stays): quiet blocks before a wave speculates in first_blocks, read
+                     * from the kernel-argument segment HERE, where tiles that stay arrive, not held in a scalar register across
+                     * the workgroup (the kernel has none to spare) */
+                    uint32_t spec_blocks = 0;
+                    if constexpr (SPEC) {
+                        FR_COLD_PARAMS(kp);
+                        spec_blocks = kp->loop_spec / (uint32_t)M;
+                    }
                     while (run != 0ull) {
                         if (!first) {
                             const uint32_t left = cap - done;
                             const uint32_t nblk = (left < len ? left : len) / (uint32_t)M;
                             if (nblk == 0u) break; /* fewer than M iterations to the cap: the exact loop below runs them */
-                            run = first_blocks<T, M>(run, nblk, done, X, Y, A, B, t, cnt, c2re, c2im, t4lim, spec_blocks);
+                            if constexpr (SPEC)
+                                run = first_blocks<T, M, true>(run, nblk, done, X, Y, A, B, t, cnt, c2re, c2im, t4lim, spec_blocks);
+                            else
+                                run = first_blocks<T, M>(run, nblk, done, X, Y, A, B, t, cnt, c2re, c2im, t4lim);
                             done += nblk * (uint32_t)M;
                         } else {
                             done = k1;
@@ -3437,6 +3458,10 @@ hipError_t launch_first_pass(const fr_kparams &p, const fr_kout &out, hipStream_
             hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
         else if (v1 && p.loop_mode == 4)
             hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
+        else if (p.loop_mode == 4 && bands == 4 && p.loop_spec != 0) /* <.., true>: the later episodes may speculate (first_blocks) */
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4, true>), grid, dim3(64), 0, stream, p, out);
+        else if (p.loop_mode == 4 && p.loop_spec != 0)
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1, true>), grid, dim3(64), 0, stream, p, out);
         else if (p.loop_mode == 4 && bands == 4)
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
         else if (p.loop_mode == 4)
@@ -3446,7 +3471,9 @@ hipError_t launch_first_pass(const fr_kparams &p, const fr_kout &out, hipStream_
         else
             hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
     } else {
-        if (p.loop_mode == 4)
+        if (p.loop_mode == 4 && p.loop_spec != 0)
+            hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1, true>), grid, dim3(64), 0, stream, p, out);
+        else if (p.loop_mode == 4)
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
         else
             hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);

@@ -38,7 +38,7 @@ for seed in range(n):
     cfg = fr.Config.from_buffer_copy(bytes(ocfg))
     f32 = rng.random() < 0.35
     op, fp = (O.F32, fr.Precision.F32) if f32 else (O.F64, fr.Precision.F64)
-    knobs = (int(rng.choice([0, 1, 2, 4, 8, 9, 10, 10, 11, 11, 11, 11, 13, 13, 14, 808, 1604, 3202, 6401])), int(rng.choice([-1, -1, 0, 2, 4])),
+    knobs = (int(rng.choice([0, 1, 2, 4, 8, 9, 10, 10, 11, 11, 11, 11, 13, 13, 14, 15, 16, 808, 1604, 3202, 6401])), int(rng.choice([-1, -1, -1, 0, 2, 4, 5])),
              int(rng.random() < 0.7), int(rng.random() < 0.5), int(rng.choice([1, 1, 1, 2, 0])))
     lib.fr_set_tile(knobs[0]); lib.fr_set_loop_mode(knobs[1]); lib.fr_set_palette(knobs[2]); lib.fr_set_cycle_shortcut(knobs[3])
     lib.fr_set_colour_filter(knobs[4])
