@@ -158,8 +158,15 @@ def loop_mix(kernel_name):
     spec = ("; quiet waves: speculative blocks of 16 unchecked iterations, one test at the end, start state kept for "
             "rollback = (96 + 2) / 16 = 6.125 (the figure used here)")
     if "first_kernel" in kernel_name or "second_kernel" in kernel_name or "queue_kernel" in kernel_name:
-        n, what = 6.125, ("scaled form; while lanes leave: unchecked blocks of 4 iterations with a |z|^2 <= T test and freeze "
-                          "per block = 26 / 4 (f32, counting per lane: 27 / 4)" + spec)
+        f32 = "<float" in kernel_name
+        if "speculative" in kernel_name:  # the first pass's form whose later episodes speculate (launched unless the view's statistics say nothing stays)
+            n, what = 6.125, ("scaled form; while lanes leave: unchecked blocks of 4 iterations with a |z|^2 <= T test and freeze "
+                              "per block = 26 / 4 (f32, counting per lane: 27 / 4)" + spec)
+        else:  # the plain form (C4: no sampled pixel at the cap, mean under 96 iterations: nothing would ever speculate)
+            n, what = (6.75, "scaled form in unchecked blocks of 4 iterations with a per-lane count: 24 arithmetic + |z|^2 <= T test + "
+                             "count + freeze per block = 27 / 4") if f32 else (
+                       6.5, "scaled form in unchecked blocks of 4 iterations: 24 arithmetic + |z|^2 <= T test + freeze per block = 26 / 4 "
+                            "(first episode, counting per lane: 27 / 4)")
     elif "strip_kernel" in kernel_name or "refill_kernel" in kernel_name or "escape kernels" in kernel_name:
         n, what = 6.125, ("scaled form X = 2re, Y = 2im, A = X^2, B = Y^2: 6 per iteration; while lanes leave: one distance add "
                           "and one compare per block of 4 = 26 / 4 (the reference as written: 8 arithmetic + 1 compare = 9)" + spec)

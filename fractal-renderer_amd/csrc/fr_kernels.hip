@@ -3546,11 +3546,18 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 
 template <typename T>
 const char *first_pass_name(const fr_kparams &p) {
-    if (p.strip_tiles == 4)
-        return p.first_only ? FR_KNAME("escape_first_kernel", "4-tile strips in episodes, every tile finished in place")
-                            : FR_KNAME("escape_first_kernel + escape_second_kernel", "4-tile strips, then persistent waves over the survivor lists");
-    return p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place")
-                        : FR_KNAME("escape_first_kernel + escape_second_kernel", "7-tile strips, then persistent waves over the survivor lists");
+    /* which form of the first pass runs (launch_first_pass): the one whose later episodes may speculate, or the plain one */
+    const bool spec = p.loop_mode == 4 && p.loop_spec != 0;
+#define FR_FIRST_NAMES(SUFFIX)                                                                                                       \
+    (p.strip_tiles == 4                                                                                                              \
+         ? (p.first_only ? FR_KNAME("escape_first_kernel", "4-tile strips in episodes, every tile finished in place" SUFFIX)         \
+                         : FR_KNAME("escape_first_kernel + escape_second_kernel",                                                    \
+                                    "4-tile strips, then persistent waves over the survivor lists" SUFFIX))                          \
+         : (p.first_only ? FR_KNAME("escape_first_kernel", "7-tile strips in episodes, every tile finished in place" SUFFIX)         \
+                         : FR_KNAME("escape_first_kernel + escape_second_kernel",                                                    \
+                                    "7-tile strips, then persistent waves over the survivor lists" SUFFIX)))
+    return spec ? FR_FIRST_NAMES("; speculative blocks in the later episodes") : FR_FIRST_NAMES("");
+#undef FR_FIRST_NAMES
 }
 
 template <typename T>
