@@ -43,10 +43,11 @@ struct fr_kparams {
      * every live lane of the wave has |z|^2 <= skip_t (see fr_kernels.hip). */
     uint32_t loop_mode;
     double skip_t;
-    /* loop_mode == 4 only: a wave whose live lanes have all stayed under skip_t for this many iterations goes on in
-     * speculative blocks of FR_SPEC_M unchecked iterations that keep their start state (fr_kernels.hip:
-     * FR_SC_SPEC_BODY); 0 = never (the host could not prove that an escape inside a block is visible at its
-     * end, or was asked not to) */
+    /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY, FR_ORBIT_ASM, FR_FB_SPEC_LOOP): a wave in which no lane has
+     * passed skip_t (loop_mode 4) / escaped (the unscaled loop) for this many iterations goes on in blocks of FR_SPEC_M
+     * unchecked iterations that keep their start state in a second register set; 0 = never (the host could not prove that an
+     * escape inside a block is visible at its end — fr_api.hip: plan_loop — was asked not to, or the view's statistics say
+     * that nothing stays).  The two-iteration scaled blocks (loop_mode 2) do not speculate. */
     uint32_t loop_spec;
     /* smooth == false only: palette[i] = packed r | g << 8 | b << 16 of an OUTSIDE pixel whose
      * escape index is i (0 .. iterations), built by fr_launch_palette; NULL = compute per pixel */

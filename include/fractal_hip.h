@@ -420,11 +420,13 @@ int fr_set_colour_filter(int enabled);
 /* Orbit-loop selector for tuning studies and tests: -1 = automatic (default); 0 = the unscaled
  * loop with an escape check every iteration; 4 / 2 = the scaled loop that checks every 4th / 2nd
  * iteration, used only where it is provably bit-identical (otherwise the call still falls back to
- * 0).  With 4 (and under -1 wherever 4 is chosen) a wave whose lanes have all stayed far inside the
- * limit for 16 iterations goes on in speculative blocks of 16 unchecked iterations that keep their start
- * state in a second register set: one test at the block's end, the block thrown away and re-run with
- * checks if it fails (only where limit^2 >= 16 and every |c| component <= limit^2 / 8: an orbit past
- * the limit then grows monotonically, so an escape inside a block cannot be missed at its end).
+ * 0).  In the four-iteration scaled loop and in the unscaled loop a wave whose lanes have all stayed quiet
+ * (far inside the limit / none escaping) for 16 iterations goes on in speculative blocks of 16 unchecked
+ * iterations that keep their start state in a second register set: one test at the block's end, the block
+ * thrown away and re-run with checks if it fails (only where 16 <= limit^2 <= 2^1000 — f32: 2^100 —, every
+ * |c| component <= limit^2 / 8 and the view's coordinates are finite: an orbit past the limit then grows
+ * monotonically and passes the limit before anything overflows, so an escape inside a block cannot be
+ * missed at its end; fr_debug_loop_plan shows the plan).
  * 5 = automatic without those speculative blocks (A/B).  Every mode produces the same bytes. */
 int fr_set_loop_mode(int mode);
 /* Tool / test hook, host arithmetic only (works without a device): the loop plan of (cfg, precision) as one launch

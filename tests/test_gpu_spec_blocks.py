@@ -126,3 +126,37 @@ def test_same_device_bytes_with_and_without_speculation_at_4k(fr):
         lib.fr_set_loop_mode(-1)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+
+
+def test_the_first_pass_runs_its_plain_form_where_nothing_stays(fr):
+    """The view's statistics decide which form of the first-pass kernel a large launch gets (fr_api.hip: decide_from_sample):
+    C4's dust — no sampled pixel at the cap, mean 44 — the plain one (the speculative form's set-up cost it 1.5 %), a deep
+    boundary view the one whose later episodes speculate; selector 5 always the plain one.  The kernel's name says which."""
+    import ctypes as C
+
+    import torch
+
+    from fractal_renderer_amd import _native
+
+    lib = _native.load()
+    w, h = 8192, 4096
+    d = torch.empty(w * h * 3, dtype=torch.uint8, device="cuda")
+    name = C.create_string_buffer(256)
+    views = {
+        "dust": (O.cli_config(w, h, O.JULIA, iterations=4096, julia_set=(-0.8, 0.156)), False),
+        "deep": (O.cli_config(w, h, iterations=4096, pos=(-0.7436447860, 0.1318252536), scale=(1e6, 1e6)), True),
+    }
+    try:
+        _native.check(lib.fr_set_profiling(1))
+        for key, (ocfg, want_spec) in views.items():
+            cfg = to_fr(fr, ocfg)
+            for mode in (-1, 5):
+                _native.check(lib.fr_set_loop_mode(mode))
+                _native.check(lib.fr_render_rows_rgb8_device(C.byref(cfg), int(fr.Precision.F64), 0, h, C.c_void_p(d.data_ptr()), d.numel(), None))
+                torch.cuda.synchronize()
+                _native.check(lib.fr_last_kernel_name(name, len(name)))
+                assert name.value.startswith(b"escape_first_kernel"), (key, mode, name.value)
+                assert (b"speculative" in name.value) == (want_spec and mode == -1), (key, mode, name.value)
+    finally:
+        lib.fr_set_loop_mode(-1)
+        lib.fr_set_profiling(0)
