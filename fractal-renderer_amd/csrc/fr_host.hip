@@ -304,6 +304,22 @@ struct CopyPool {
 void destroy_copy_pool(CopyPool *pool) { delete pool; }
 
 namespace {
+int copy_helpers();
+bool staging_enabled();
+}  // namespace
+
+/* the staged road's helper threads, made with the context (they sleep between frames): started by the first frame of 3 MiB
+ * and more they cost that frame 0.1-0.3 ms (bench.py gui_latency, 1500 x 1000: first call 0.28-0.51 ms against a 0.18 median) */
+CopyPool *create_copy_pool() {
+    if (!staging_enabled() || copy_helpers() <= 0) return nullptr;
+    try {
+        return new CopyPool(copy_helpers());
+    } catch (...) {
+        return nullptr; /* best effort: the first large frame tries again */
+    }
+}
+
+namespace {
 
 bool staging_enabled() {
     static const bool on = [] {
