@@ -10,6 +10,10 @@ ARGS="--no-extras --steps 10 --warmup 2 $*"   # the default bench's step counts
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/pmc1" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc1.json" 2> "$OUT/pmc1.err"
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d "$OUT/pmc2" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc2.json" 2> "$OUT/pmc2.err"
+# the box's own reference (boxes of the pool differ by +-4 % in sustained clock): the same workload without the profiler,
+# speculative blocks on (default) and off (--loop-mode 5), back to back
+python3 "$REPO/bench.py" $ARGS --no-cpu-baseline > "$OUT/bench_plain.json" 2> "$OUT/plain.err"
+python3 "$REPO/bench.py" $ARGS --no-cpu-baseline --loop-mode 5 > "$OUT/bench_nospec.json" 2> "$OUT/nospec.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmcw.json" 2> "$OUT/pmcw.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o b -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmcf.json" 2> "$OUT/pmcf.err"
 python3 - "$OUT" "$TAG" "$ARGS" > "$OUT/summary.txt" <<'PY'
@@ -40,12 +44,14 @@ for sub in ("stats", "pmc1", "pmc2", "pmc_write", "pmc_fetch"):
                        "group by kernel_name, counter_name order by 1, 2"):
             if "escape" in r[0] or "fern" in r[0]:
                 print("%s, %s, %d, %.6g" % r)
-for name in ("bench_stats.json",):
+for name, what in (("bench_stats.json", "bench.py line of the stats pass"),
+                   ("bench_plain.json", "same box, no profiler, speculative blocks on (default)"),
+                   ("bench_nospec.json", "same box, no profiler, speculative blocks OFF (--loop-mode 5: round 3's loops)")):
     try:
         d = json.loads(open(os.path.join(root, name)).read().strip().splitlines()[-1])
-        print("== bench.py line of the stats pass: ms_per_step %.3f kernel_ms_avg %.3f value %.4g frac %.4f kernel %s" % (
-            d["ms_per_step"], d["kernel_ms_avg"], d["value"], d["roofline"]["frac"], d["roofline"]["kernel"]))
+        print("== %s: ms_per_step %.3f kernel_ms_avg %.3f value %.4g frac %.4f kernel %s" % (
+            what, d["ms_per_step"], d["kernel_ms_avg"], d["value"], d["roofline"]["frac"], d["roofline"]["kernel"]))
     except Exception as e:  # noqa: BLE001
-        print("== no bench line (%r)" % e)
+        print("== %s: no bench line (%r)" % (what, e))
 PY
 cat "$OUT/summary.txt"
