@@ -472,6 +472,27 @@ def run_single(args, torch, fr, lib, native):
         print(json.dumps(out), flush=True)
         return
 
+    # The box's own reference, right behind the timed steps (boxes of the pool differ by +-4 % in sustained clock, so a line
+    # read on its own cannot say what a change bought): the same workload with the speculative long blocks switched off
+    # (fr_set_loop_mode(5): round 3's loops).  Not part of `value`.
+    if args.loop_mode == -1 and args.tile == 0 and not args.force_blocks:
+        on_img = img.clone()  # (measure() renders into the same buffer)
+        native.check(lib.fr_set_loop_mode(5))
+        try:
+            off = sg.measure(cfg, prec, max(3, args.steps // 2), 1)
+        finally:
+            native.check(lib.fr_set_loop_mode(args.loop_mode))
+        out["roofline"]["same_box_without_speculative_blocks"] = {
+            "kernel_ms_avg": off["kernel_ms"], "frac": FLOPS_PER_ITERATION * total / (off["kernel_ms"] * 1e-3) / 1e12 / (
+                FP32_VECTOR_PEAK_TFLOPS if args.precision == "f32" else FP64_VECTOR_PEAK_TFLOPS),
+            "speculative_blocks_gain": 1.0 - m["kernel_ms"] / off["kernel_ms"],
+            "bytes_identical": bool(torch.equal(off["image"], on_img)),
+            "note": "fr_set_loop_mode(5) — the loops of round 3, same process, same box, measured right behind the timed steps; not "
+                    "part of `value`",
+        }
+        del on_img
+        img = sg.render(cfg, prec)  # (the reference image of the checks below: rendered with the default loops again)
+
     ref = img.clone()
     # The other millisecond-scale BASELINE configs right behind the headline, while the device is in the state the
     # headline was measured in: seconds of sustained load (the host-path legs, C3, C5 below) leave it at a lower clock for
