@@ -194,7 +194,6 @@ int Ctx::create(int device) {
             if (e == hipSuccess) e = hipStreamSynchronize(stream2);
             if (e != hipSuccess) (void)hipGetLastError();
         }
-        if (!copy_pool) copy_pool = create_copy_pool(); /* ... and the helper threads of the staged road (sleeping until a frame of 3 MiB comes) */
     }
     return FR_OK;
 }

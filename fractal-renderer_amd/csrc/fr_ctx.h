@@ -228,7 +228,6 @@ class ChunkPinner {
 };
 void prefault(void *ptr, size_t len);
 void destroy_copy_pool(CopyPool *pool); /* stops and joins the threads (fr_host.hip) */
-CopyPool *create_copy_pool();           /* the staged road's helper threads, or NULL (none wanted / could not be started) */
 
 /* per-thread kernel timing (fr_set_profiling / fr_last_kernel_ms) */
 struct Profiling {

@@ -304,22 +304,6 @@ struct CopyPool {
 void destroy_copy_pool(CopyPool *pool) { delete pool; }
 
 namespace {
-int copy_helpers();
-bool staging_enabled();
-}  // namespace
-
-/* the staged road's helper threads, made with the context (they sleep between frames): started by the first frame of 3 MiB
- * and more they cost that frame 0.1-0.3 ms (bench.py gui_latency, 1500 x 1000: first call 0.28-0.51 ms against a 0.18 median) */
-CopyPool *create_copy_pool() {
-    if (!staging_enabled() || copy_helpers() <= 0) return nullptr;
-    try {
-        return new CopyPool(copy_helpers());
-    } catch (...) {
-        return nullptr; /* best effort: the first large frame tries again */
-    }
-}
-
-namespace {
 
 bool staging_enabled() {
     static const bool on = [] {
@@ -457,6 +441,9 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     /* the copy out: the caller alone for small bands, with the helpers from 2 MiB a band; pages the caller has never
      * touched (a fresh Vec) are faulted in — huge-page hint, all threads — while the first band renders */
     const int helpers = need >= ((size_t)3 << 20) ? copy_helpers() : 0;
+    /* made by the first frame that wants them (0.1-0.3 ms of that frame), NOT with the context: threads that had slept since
+     * the context's creation answered their first piece 26-30 ms late in 3 of 8 bench.py runs (gui_latency, 1500 x 1000:
+     * "copied out at 29.8 ms" with everything enqueued at 0.04); threads started here never did in a dozen runs */
     if (helpers > 0 && !ctx.copy_pool) ctx.copy_pool = new CopyPool(helpers);
     CopyPool *pool = helpers > 0 ? ctx.copy_pool : nullptr;
 
