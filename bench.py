@@ -476,7 +476,9 @@ def run_single(args, torch, fr, lib, native):
     # read on its own cannot say what a change bought): the same workload with the speculative long blocks switched off
     # (fr_set_loop_mode(5): round 3's loops).  Not part of `value`.
     if args.loop_mode == -1 and args.tile == 0 and not args.force_blocks:
-        on_img = img.clone()  # (measure() renders into the same buffer)
+        # (measure() renders into the same buffer; no second 805 MB allocation for the comparison: two sums of the bytes)
+        flat = img.reshape(-1)
+        on_sums = (int(flat.sum(dtype=torch.int64)), int(flat[1::2].sum(dtype=torch.int64)))
         native.check(lib.fr_set_loop_mode(5))
         try:
             off = sg.measure(cfg, prec, max(3, args.steps // 2), 1)
@@ -486,11 +488,11 @@ def run_single(args, torch, fr, lib, native):
             "kernel_ms_avg": off["kernel_ms"], "frac": FLOPS_PER_ITERATION * total / (off["kernel_ms"] * 1e-3) / 1e12 / (
                 FP32_VECTOR_PEAK_TFLOPS if args.precision == "f32" else FP64_VECTOR_PEAK_TFLOPS),
             "speculative_blocks_gain": 1.0 - m["kernel_ms"] / off["kernel_ms"],
-            "bytes_identical": bool(torch.equal(off["image"], on_img)),
+            "byte_sums_identical": (int(off["image"].reshape(-1).sum(dtype=torch.int64)),
+                                    int(off["image"].reshape(-1)[1::2].sum(dtype=torch.int64))) == on_sums,
             "note": "fr_set_loop_mode(5) — the loops of round 3, same process, same box, measured right behind the timed steps; not "
                     "part of `value`",
         }
-        del on_img
         img = sg.render(cfg, prec)  # (the reference image of the checks below: rendered with the default loops again)
 
     ref = img.clone()

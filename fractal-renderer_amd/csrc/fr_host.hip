@@ -441,9 +441,7 @@ int host_render_staged(Ctx &ctx, const fr_config *cfg, int precision, const Opts
     /* the copy out: the caller alone for small bands, with the helpers from 2 MiB a band; pages the caller has never
      * touched (a fresh Vec) are faulted in — huge-page hint, all threads — while the first band renders */
     const int helpers = need >= ((size_t)3 << 20) ? copy_helpers() : 0;
-    /* made by the first frame that wants them (0.1-0.3 ms of that frame), NOT with the context: threads that had slept since
-     * the context's creation answered their first piece 26-30 ms late in 3 of 8 bench.py runs (gui_latency, 1500 x 1000:
-     * "copied out at 29.8 ms" with everything enqueued at 0.04); threads started here never did in a dozen runs */
+    /* made by the first frame that wants them: 0.1-0.3 ms of that frame */
     if (helpers > 0 && !ctx.copy_pool) ctx.copy_pool = new CopyPool(helpers);
     CopyPool *pool = helpers > 0 ? ctx.copy_pool : nullptr;
 
