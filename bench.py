@@ -479,11 +479,15 @@ def run_single(args, torch, fr, lib, native):
         # (measure() renders into the same buffer; no second 805 MB allocation for the comparison: two sums of the bytes)
         flat = img.reshape(-1)
         on_sums = (int(flat.sum(dtype=torch.int64)), int(flat[1::2].sum(dtype=torch.int64)))
+        # reproduction aid: the second 805 MB device allocation, alive across the measurement below, behind which the first
+        # two-band host frame of the process stalled 25-30 ms
+        clone_probe = img.clone() if os.environ.get("FR_BENCH_DEBUG_CLONE") == "1" else None
         native.check(lib.fr_set_loop_mode(5))
         try:
             off = sg.measure(cfg, prec, max(3, args.steps // 2), 1)
         finally:
             native.check(lib.fr_set_loop_mode(args.loop_mode))
+        del clone_probe
         out["roofline"]["same_box_without_speculative_blocks"] = {
             "kernel_ms_avg": off["kernel_ms"], "frac": FLOPS_PER_ITERATION * total / (off["kernel_ms"] * 1e-3) / 1e12 / (
                 FP32_VECTOR_PEAK_TFLOPS if args.precision == "f32" else FP64_VECTOR_PEAK_TFLOPS),

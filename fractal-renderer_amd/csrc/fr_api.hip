@@ -194,6 +194,19 @@ int Ctx::create(int device) {
             if (e == hipSuccess) e = hipStreamSynchronize(stream2);
             if (e != hipSuccess) (void)hipGetLastError();
         }
+        /* ... and one KERNEL on each of the two band streams (the copy kernel, 4 KB, flags 6 and 7 — frames use 0 to 3): a
+         * stream gets its hardware queue at its first kernel, and where the process has meanwhile made large device
+         * allocations of its own that first kernel came 25-30 ms late — the first two-band host frame of bench.py runs that
+         * had cloned the 805 MB image (5 of 12).  Made here, while the process is small. */
+        if (rgb.ptr && stage_dev && stage_flags_dev && stage_counters) {
+            hipError_t e = fr_launch_copy_out(rgb.ptr, stage_dev, 4096, stage_counters + 6, stage_flags_dev + 6, 1ull, stream);
+            if (e == hipSuccess)
+                e = fr_launch_copy_out(static_cast<char *>(rgb.ptr) + 4096, static_cast<char *>(stage_dev) + 4096, 4096, stage_counters + 7,
+                                       stage_flags_dev + 7, 1ull, stream2);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream2);
+            if (e != hipSuccess) (void)hipGetLastError();
+        }
     }
     return FR_OK;
 }
