@@ -344,6 +344,12 @@ def gui_latency(fr, lib, native):
         native.check(lib.fr_last_kernel_name(kname, len(kname)))
         return kname.value.decode()
 
+    # the Python side of the two entry points once, on a 16 x 16 frame of its own (another shape, another view): what the
+    # first_call_ms of the small frames measures is the LIBRARY's first call for a shape — ctypes' own first-call work
+    # (argument conversion set-up, ~50 us) is a visible share of a 0.09 ms frame
+    tiny = make_config(fr, "default", 16, 50)
+    fr.get_image_rows(tiny, 0, 16, fr.Precision.F64, out=np.ones((16, 16, 3), dtype=np.uint8))
+    fr.get_image_rgba(tiny, fr.Precision.F64, out=np.ones((16, 16, 4), dtype=np.uint8))
     for view in ("default", "julia", "filled_julia", "thin_dust"):
         rows = {}
         for label, w, h, it in (frames if view in ("default", "julia") else frames[2:]):
@@ -405,7 +411,8 @@ def gui_latency(fr, lib, native):
         out["mandelbrot default view" if view == "default" else "julia -0.8+0.156i (C4's view)"] = rows
     native.check(lib.fr_set_profiling(0))
     out["note"] = ("fr_render_rows_rgb8 / fr_render_rows_rgba8 into a resident host buffer, f64, wall time of the call (kernel + D2H "
-                   "+ call overhead); first_call_ms = the first call of this process for that frame shape")
+                   "+ call overhead); first_call_ms = the first call of this process for that frame shape (the Python wrappers "
+                   "have been called once before, on a 16 x 16 frame)")
     return out
 
 
