@@ -17,6 +17,18 @@ int main(void) {
     fr_config_new(&cfg, FR_ALGO_MANDELBROT);
     if (cfg.iterations != 50 || cfg.primary_color.g != 255) return 12;
     if (fr_device_count(&n) != FR_OK) return 13;
+    { /* the loop plan is host arithmetic: it answers without a device (include/fractal_hip.h: fr_debug_loop_plan) */
+        uint32_t mode = 99, quiet = 99;
+        double skip = -1.0;
+        fr_config view;
+        fr_config_new(&view, FR_ALGO_MANDELBROT);
+        view.width = 1920, view.height = 1080, view.iterations = 1024, view.pos.re = -0.6;
+        if (fr_debug_loop_plan(&view, FR_PRECISION_F64, &mode, &skip, &quiet) != FR_OK) return 30;
+        if (mode != 4 || !(skip > 4.5 && skip < 7.5) || quiet != 16) return 31; /* blocks of four, speculative after 16 quiet iterations */
+        view.limit = 2.0; /* limit^2 = 4 < 16: nothing may be skipped, nothing speculated */
+        if (fr_debug_loop_plan(&view, FR_PRECISION_F64, &mode, &skip, &quiet) != FR_OK || mode != 0 || quiet != 0) return 32;
+        if (fr_debug_loop_plan(&view, FR_PRECISION_F64, 0, &skip, &quiet) == FR_OK) return 33;
+    }
     if (n == 0) { /* no GPU: every compute call must fail loudly */
         rc = fr_recursive(50, start, c, 65536.0, &pos, &iters);
         if (rc != FR_ERR_NO_DEVICE || strlen(fr_last_error()) == 0) return 14;
