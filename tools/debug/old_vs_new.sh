@@ -1,5 +1,5 @@
 #!/bin/bash
-# The library of the round's start (tools/debug/variants/libfractal_hip_old.so, built by hand from commit b01bede) against the
+# The library of the round's start (tools/debug/variants/libfractal_hip_old.so: tools/debug/build_variants.sh builds it from commit b01bede) against the
 # current one, bench.py --no-extras per line, alternating processes on ONE box (a box's clock state differs by more than a change).
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$REPO/fractal-renderer_amd/libfractal_hip.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Block length of the speculative blocks (FR_SPEC_M = 8 / 16 / 32): the library variants under tools/debug/variants
-# (built by hand with -DFR_SPEC_M=..) are copied over the box's scratch copy of the library in turn; bench.py's headline only.
+# (tools/debug/build_variants.sh) are copied over the box's scratch copy of the library in turn; bench.py's headline only.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$REPO/fractal-renderer_amd/libfractal_hip.so
 cp "$LIB" /tmp/lib_m16.so
