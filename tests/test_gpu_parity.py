@@ -842,6 +842,9 @@ def test_bench_smoke_small():
     assert d["roofline"]["achieved"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["gpu_bytes_identical_on_sample"] is True
     assert d["cpu_baseline"]["gpu_iteration_sum_identical_on_sample"] is True
+    # the box's own reference: the same workload without the speculative blocks, same bytes
+    ref = d["roofline"]["same_box_without_speculative_blocks"]
+    assert ref["byte_sums_identical"] is True and ref["kernel_ms_avg"] > 0 and -0.5 < ref["speculative_blocks_gain"] < 0.5
 
 
 def test_rccl_p2p_call_pattern_self_send():
