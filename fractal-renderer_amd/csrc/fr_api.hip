@@ -742,10 +742,14 @@ struct Decision {
 static Decision decide_from_sample(const double st[7], uint64_t tiles, const fr_kparams &p, int precision, bool two_pass_ok) {
     const double lanes = 64.0 * st[2];
     const double capped = st[3] / lanes, waste = st[5] / st[0], mean = st[0] / lanes, handed = st[4] / lanes;
-    /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY) pay where waves stay quiet for dozens of iterations.  A view
-     * in which no sampled pixel reaches the cap and orbits are short on average has no such waves — C4's dust: mean 44, and
-     * the first pass's speculative form costs it 1.5 % in set-up per tile that stays an episode — so it is rendered by the
-     * kernels without them.  (Long orbits that all escape in the end — filaments at high caps — still gain: mean >= 96.) */
+    /* Speculative long blocks (fr_kernels.hip: FR_SC_SPEC_BODY) pay where waves stay quiet for dozens of iterations.  In a
+     * view in which no sampled pixel reaches the cap and orbits are short on average, the tiles that stay in the TWO-PASS
+     * render's first kernel have no such waves (their stragglers leave for the lists) — C4's dust: mean 44, and the first
+     * pass's speculative form costs it 1.5 % in set-up per tile that stays an episode — so that kernel runs in its plain form
+     * there.  Only that kernel: where stragglers are finished in place (strips, the first pass alone, the unscaled loop of a
+     * Julia constant with a zero component) they ARE the quiet waves, however short the mean — the dendrite c = i at 1920 x
+     * 1080, mean 6.5: 0.058 ms without the blocks, 0.035 with — and the blocks cost those loops nothing when unused.
+     * (Long orbits that all escape in the end — filaments at high caps — gain in the first kernel too: mean >= 96.) */
     Decision d{2, false, 0u, capped < 0.0005 && mean < 96.0};
     if (tiles >= kMidRuleTiles) {
         if (capped >= 0.10 && waste < 0.01)
@@ -916,7 +920,7 @@ int render_device(Ctx &ctx, const fr_config *cfg, fr_kparams &p, int precision, 
     int pending = -1;
     const int hint = o.kernel_hint != -2 ? o.kernel_hint
                                          : choose_kernel(ctx, cfg, p, precision, o, stream, true, &one_band, &strip_tiles, &pending, &no_spec);
-    if (no_spec) p.loop_spec = 0; /* the view's statistics: nothing stays (decide_from_sample) */
+    p.first_no_spec = no_spec ? 1u : 0u; /* the view's statistics: nothing stays (decide_from_sample) — the two-pass render's first kernel runs in its plain form */
     struct SampleGuard { /* whatever happens below, a slot that was promised a sample gets it (or is freed) */
         Ctx &ctx;
         int idx;

@@ -49,6 +49,8 @@ struct fr_kparams {
      * escape inside a block is visible at its end — fr_api.hip: plan_loop — was asked not to, or the view's statistics say
      * that nothing stays).  The two-iteration scaled blocks (loop_mode 2) do not speculate. */
     uint32_t loop_spec;
+    uint32_t first_no_spec; /* 1: the two-pass render's first kernel runs in its plain form whatever loop_spec says (the view's
+                             * statistics: nothing stays in its tiles; fr_api.hip: decide_from_sample) */
     /* smooth == false only: palette[i] = packed r | g << 8 | b << 16 of an OUTSIDE pixel whose
      * escape index is i (0 .. iterations), built by fr_launch_palette; NULL = compute per pixel */
     const uint32_t *palette;

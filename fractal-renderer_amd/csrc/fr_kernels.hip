@@ -3437,6 +3437,12 @@ hipError_t launch_queue(const fr_kparams &p, const fr_kout &out, hipStream_t str
     return launch_queue_form<T, 2, 0>(p, out, stream);
 }
 
+/* the first-pass kernel's form: later episodes in speculative blocks where the plan allows them, unless this is the two-pass
+ * render (tiles hand their stragglers over) of a view whose statistics say that nothing stays */
+static bool first_pass_speculates(const fr_kparams &p) {
+    return p.loop_mode == 4 && p.loop_spec != 0 && !(p.first_no_spec && !p.first_only);
+}
+
 /* Two passes, RGB output only; needs the survivor lists and p.work_counter (all counters zeroed on the launch
  * stream by the caller) and 0 < p.first_cap < p.iterations */
 template <typename T, int kStripTiles>
@@ -3458,9 +3464,9 @@ hipError_t launch_first_pass(const fr_kparams &p, const fr_kout &out, hipStream_
             hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
         else if (v1 && p.loop_mode == 4)
             hipLaunchKernelGGL((escape_first_v1_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
-        else if (p.loop_mode == 4 && bands == 4 && p.loop_spec != 0) /* <.., true>: the later episodes may speculate (first_blocks) */
+        else if (bands == 4 && first_pass_speculates(p)) /* <.., true>: the later episodes may speculate (first_blocks) */
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4, true>), grid, dim3(64), 0, stream, p, out);
-        else if (p.loop_mode == 4 && p.loop_spec != 0)
+        else if (first_pass_speculates(p))
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1, true>), grid, dim3(64), 0, stream, p, out);
         else if (p.loop_mode == 4 && bands == 4)
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 4>), grid, dim3(64), 0, stream, p, out);
@@ -3471,7 +3477,7 @@ hipError_t launch_first_pass(const fr_kparams &p, const fr_kout &out, hipStream_
         else
             hipLaunchKernelGGL((escape_first_kernel<T, 2, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
     } else {
-        if (p.loop_mode == 4 && p.loop_spec != 0)
+        if (first_pass_speculates(p))
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1, true>), grid, dim3(64), 0, stream, p, out);
         else if (p.loop_mode == 4)
             hipLaunchKernelGGL((escape_first_kernel<T, 4, kStripTiles, 1>), grid, dim3(64), 0, stream, p, out);
@@ -3547,7 +3553,7 @@ hipError_t launch_tile(const fr_kparams &p, int mode, const fr_kout &out, hipStr
 template <typename T>
 const char *first_pass_name(const fr_kparams &p) {
     /* which form of the first pass runs (launch_first_pass): the one whose later episodes may speculate, or the plain one */
-    const bool spec = p.loop_mode == 4 && p.loop_spec != 0;
+    const bool spec = first_pass_speculates(p);
 #define FR_FIRST_NAMES(SUFFIX)                                                                                                       \
     (p.strip_tiles == 4                                                                                                              \
          ? (p.first_only ? FR_KNAME("escape_first_kernel", "4-tile strips in episodes, every tile finished in place" SUFFIX)         \
